@@ -1,0 +1,106 @@
+"""Pins the CPU oracle (oracle/) before anything is compared with it.
+
+The reference's own tests hold no literal digests for this path (they assert equality between
+implementations, TestChecksumImplsComputeSameValues.java:43-101, and structure, TestChecksum.java:47-80),
+so the oracle is pinned by: the digests of the reference's two Java CRC tables, published known-answer
+vectors, and vectors produced by zlib / hashlib / the parsed Java CRC32C table (tests/golden/gen_golden.py).
+"""
+import hashlib
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import make_data
+
+
+def test_tables_equal_reference_java_tables(reference_tables):
+    for name, poly in (("CRC32", 0xEDB88320), ("CRC32C", 0x82F63B78)):
+        t = oracle.crc_table(poly)
+        assert len(t) == 2048  # ChecksumByteBuffer.java:57
+        rec = reference_tables[name]
+        assert hashlib.sha256(struct.pack("<2048I", *t)).hexdigest() == rec["sha256"]
+        for idx, val in rec["samples"].items():
+            assert t[int(idx)] == int(val, 16)
+
+
+def test_kat(vectors):
+    for rec in vectors["kat"]:
+        d = make_data(rec["data"])
+        assert oracle.compute(rec["type"], rec["bpc"], d).hex() == "".join(rec["sums_hex"]), rec["name"]
+
+
+def test_compute_golden(vectors):
+    for rec in vectors["compute"]:
+        d = make_data(rec["data"])
+        got = oracle.compute(rec["type"], rec["bpc"], d)
+        assert got.hex() == "".join(rec["sums_hex"]), rec["name"]
+
+
+def test_verify_golden(vectors):
+    for v in vectors["verify"]:
+        sd = make_data(v["stored_data"])
+        stored = oracle.compute(v["type"], v["bpc"], sd)
+        ds = oracle.DIGEST_SIZE[v["type"]]
+        if v["stored_count"] >= 0:
+            stored = stored[: v["stored_count"] * ds]
+        d = sd[v["data_off"]: v["data_off"] + v["data_len"]].copy()
+        for o in v["flips"]:
+            d[o] ^= 0xFF
+        rc, first = oracle.verify(v["type"], v["bpc"], d, stored, v["start_index"])
+        assert (rc, first) == (v["rc"], v["first_mismatch"]), v["name"]
+
+
+def test_incremental_update_semantics():
+    # TestChecksumByteBuffer.java:78-91: byte-at-a-time and cumulative updates agree with one-shot
+    L = oracle.lib()
+    import ctypes
+    tab = (ctypes.c_uint32 * 2048)()
+    L.oracle_crc_make_table(0xEDB88320, tab)
+    rng = np.random.default_rng(7)
+    for _ in range(50):
+        d = rng.integers(0, 256, 1024, dtype=np.uint8).tobytes()
+        crc = 0xFFFFFFFF
+        for i in range(len(d)):
+            crc = L.oracle_crc_update(crc, d[i:i + 1], 1, tab)
+            if i % 97 == 0:
+                assert (~crc) & 0xFFFFFFFF == zlib.crc32(d[: i + 1])
+        assert (~crc) & 0xFFFFFFFF == zlib.crc32(d)
+        cut = int(rng.integers(0, 1024))
+        c2 = L.oracle_crc_update(L.oracle_crc_update(0xFFFFFFFF, d[:cut], cut, tab), d[cut:], 1024 - cut, tab)
+        assert c2 == crc
+
+
+def test_structure_like_reference_tests():
+    # TestChecksum.java:47-62: 55 bytes at bpc 10 -> 6 checksums; :67-80 a changed byte changes them
+    d = oracle.splitmix64(3, 55)
+    for t in (oracle.CRC32, oracle.CRC32C, oracle.SHA256, oracle.MD5):
+        s = oracle.compute(t, 10, d)
+        assert len(s) == 6 * oracle.DIGEST_SIZE[t]
+        d2 = d.copy()
+        d2[50] ^= 1
+        s2 = oracle.compute(t, 10, d2)
+        assert s2 != s and s2[: 5 * oracle.DIGEST_SIZE[t]] == s[: 5 * oracle.DIGEST_SIZE[t]]
+    assert oracle.compute(oracle.NONE, 10, d) == b""
+    assert oracle.compute(oracle.CRC32, 10, np.zeros(0, np.uint8)) == b""
+    with pytest.raises(ValueError):
+        oracle.compute(9, 10, d)
+    with pytest.raises(ValueError):
+        oracle.compute(oracle.CRC32, 0, d)
+
+
+def test_random_against_zlib_hashlib():
+    rng = np.random.default_rng(11)
+    for _ in range(40):
+        n = int(rng.integers(0, 70000))
+        bpc = int(rng.integers(1, 20000))
+        d = rng.integers(0, 256, n, dtype=np.uint8)
+        b = d.tobytes()
+        exp = b"".join(struct.pack(">I", zlib.crc32(b[o:o + bpc])) for o in range(0, n, bpc))
+        assert oracle.compute(oracle.CRC32, bpc, d) == exp
+        exp = b"".join(hashlib.sha256(b[o:o + bpc]).digest() for o in range(0, n, bpc))
+        assert oracle.compute(oracle.SHA256, bpc, d) == exp
+        exp = b"".join(hashlib.md5(b[o:o + bpc]).digest() for o in range(0, n, bpc))
+        assert oracle.compute(oracle.MD5, bpc, d) == exp
