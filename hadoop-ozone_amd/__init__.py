@@ -1,0 +1,10 @@
+"""MI355X-native per-chunk data checksumming for Ozone (CRC32 / CRC32C / SHA-256 / MD5 per
+bytes-per-checksum window).
+
+  native    ctypes view of the C-ABI HIP library (csrc/libozcs.so, include/ozone_checksum.h)
+  checksum  host-side mirror of the reference interface: Checksum, ChecksumData,
+            OzoneChecksumException, ChecksumType (hadoop-hdds/common/.../ozone/common/)
+"""
+from . import native  # noqa: F401
+from .checksum import (Checksum, ChecksumData, ChecksumType,  # noqa: F401
+                       OzoneChecksumException)

@@ -1,0 +1,259 @@
+"""Host-side mirror of the reference's checksum interface, over the C-ABI HIP library.
+
+Mirrors, name for name and with the same argument meaning and error behaviour:
+  Checksum                 hadoop-hdds/common/src/main/java/org/apache/hadoop/ozone/common/Checksum.java:43-299
+  ChecksumData             .../ozone/common/ChecksumData.java:34-192
+  OzoneChecksumException   .../ozone/common/OzoneChecksumException.java:29-66
+  ChecksumType             hadoop-hdds/interface-client/src/main/proto/DatanodeClientProtocol.proto:384-390
+
+Every digest is computed by the GPU library (native.py); nothing here hashes on the CPU.
+"""
+import ctypes
+import enum
+
+from . import native
+
+
+class ChecksumType(enum.IntEnum):
+    NONE = 1
+    CRC32 = 2
+    CRC32C = 3
+    SHA256 = 4
+    MD5 = 5
+
+
+class OzoneChecksumException(IOError):
+    """OzoneChecksumException.java:29-66 (an IOException there, so callers fail over to the next replica)."""
+
+    def __init__(self, arg):
+        if isinstance(arg, ChecksumType) or (isinstance(arg, tuple) and arg and arg[0] == "type"):
+            t = arg if isinstance(arg, ChecksumType) else arg[1]
+            msg = "Unrecognized ChecksumType: %s" % (t.name if isinstance(t, ChecksumType) else t)  # :43-47
+            self.index = None
+        elif isinstance(arg, int):
+            msg = "Checksum mismatch at index %d" % arg  # :35-37
+            self.index = arg
+        else:
+            msg = str(arg)  # :63-65
+            self.index = None
+        super().__init__(msg)
+
+
+class ChecksumData:
+    """ChecksumData.java:34-192: {type, bytesPerChecksum, list of digests}."""
+
+    def __init__(self, checksumType, bytesPerChecksum, checksums=()):
+        self.type = checksumType
+        self.bytesPerChecksum = bytesPerChecksum
+        self.checksums = [bytes(c) for c in checksums]
+
+    def getChecksumType(self):
+        return self.type
+
+    def getBytesPerChecksum(self):
+        return self.bytesPerChecksum
+
+    def getChecksums(self):
+        return self.checksums
+
+    def verifyChecksumDataMatches(self, that, startIndex):
+        """ChecksumData.java:117-149: this[startIndex + i] must equal that[i] for every i."""
+        if len(self.checksums) == 0:
+            raise OzoneChecksumException("Original checksumData has no checksums")
+        if len(that.checksums) == 0:
+            raise OzoneChecksumException("Computed checksumData has no checksums")
+        n = len(that.checksums)
+        for index in range(n):
+            if startIndex + index >= len(self.checksums) or startIndex + index < 0:
+                raise OzoneChecksumException(
+                    "Computed checksum has %d number of checksums. Original checksum has %d number of checksums "
+                    "starting from index %d" % (n, len(self.checksums) - startIndex, startIndex))
+            if self.checksums[startIndex + index] != that.checksums[index]:
+                raise OzoneChecksumException(index)
+        return True
+
+    def __eq__(self, other):  # :156-182
+        return (isinstance(other, ChecksumData) and self.type == other.type
+                and self.bytesPerChecksum == other.bytesPerChecksum and self.checksums == other.checksums)
+
+    def __hash__(self):
+        return hash((int(self.type), self.bytesPerChecksum, tuple(self.checksums)))
+
+    def __repr__(self):
+        return "ChecksumData(%s, %d, %d checksums)" % (getattr(self.type, "name", self.type),
+                                                      self.bytesPerChecksum, len(self.checksums))
+
+    # ---- ContainerProtos.ChecksumData wire form (DatanodeClientProtocol.proto:378-382) ----
+    def getProtoBufMessage(self):
+        """Serialised ContainerProtos.ChecksumData: type = 1 (enum), bytesPerChecksum = 2 (uint32),
+        checksums = 3 (repeated bytes) -- what ChecksumData.getProtoBufMessage().toByteArray() yields."""
+        out = bytearray()
+        out += b"\x08" + _varint(int(self.type))
+        out += b"\x10" + _varint(self.bytesPerChecksum)
+        for c in self.checksums:
+            out += b"\x1a" + _varint(len(c)) + c
+        return bytes(out)
+
+    @staticmethod
+    def getFromProtoBuf(buf):
+        """Inverse of getProtoBufMessage (ChecksumData.java:94-102)."""
+        if buf is None:
+            raise ValueError("checksumDataProto is null")  # Preconditions.checkNotNull, :96
+        t, bpc, sums, pos, n = None, None, [], 0, len(buf)
+        while pos < n:
+            key, pos = _read_varint(buf, pos)
+            field, wt = key >> 3, key & 7
+            if wt == 0:
+                v, pos = _read_varint(buf, pos)
+                if field == 1:
+                    t = v
+                elif field == 2:
+                    bpc = v
+            elif wt == 2:
+                ln, pos = _read_varint(buf, pos)
+                if field == 3:
+                    sums.append(bytes(buf[pos:pos + ln]))
+                pos += ln
+            else:
+                raise ValueError("unsupported wire type %d" % wt)
+        if t is None or bpc is None:
+            raise ValueError("required field missing")  # both are `required` in the proto
+        return ChecksumData(ChecksumType(t), bpc, sums)
+
+
+def _varint(v):
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        if v:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            return bytes(out)
+
+
+def _read_varint(buf, pos):
+    shift = v = 0
+    while True:
+        b = buf[pos]
+        pos += 1
+        v |= (b & 0x7F) << shift
+        if not b & 0x80:
+            return v, pos
+        shift += 7
+
+
+def _split(raw, ds):
+    return [raw[i:i + ds] for i in range(0, len(raw), ds)]
+
+
+class Checksum:
+    """Checksum.java:43-299.  Not thread safe in the reference (:41); this mirror keeps no state."""
+
+    def __init__(self, type, bytesPerChecksum):  # noqa: A002 - the reference's parameter name
+        self.checksumType = type
+        self.bytesPerChecksum = bytesPerChecksum
+
+    @staticmethod
+    def int2ByteString(n):
+        """Checksum.java:62-64: Guava Ints.toByteArray -> 4 bytes big-endian."""
+        return (n & 0xFFFFFFFF).to_bytes(4, "big")
+
+    def computeChecksum(self, data, off=None, length=None):
+        """The five computeChecksum overloads (Checksum.java:119-177).
+
+        data: bytes-like (byte[] / ByteBuffer overloads; off/length as in computeChecksum(byte[],int,int)),
+        or a list of bytes-like (the List<ByteString> / ChunkBuffer-of-list overloads, one element per
+        window; an element longer than bytesPerChecksum contributes only its first bytesPerChecksum
+        bytes, Checksum.java:186-198 over ChunkBufferImplWithByteBufferList.java:180-204)."""
+        t = self.checksumType
+        if t == ChecksumType.NONE:
+            return ChecksumData(t, self.bytesPerChecksum)  # :157-160
+        try:
+            ct = ChecksumType(int(t))
+        except (ValueError, TypeError):
+            raise OzoneChecksumException(("type", t))  # :163-167
+        ds = native.DIGEST_SIZE[int(ct)]
+        bpc = self.bytesPerChecksum
+        if bpc <= 0:
+            raise ValueError("bytesPerChecksum must be positive")  # ChunkBuffer.iterate rejects it
+        if isinstance(data, (list, tuple)):
+            return ChecksumData(ct, bpc, self._compute_list(int(ct), bpc, ds, data))
+        mv = memoryview(data).cast("B") if not isinstance(data, (bytes, bytearray)) else memoryview(data)
+        if off is not None:
+            mv = mv[off:off + length]
+        if len(mv) == 0:
+            return ChecksumData(ct, bpc, [])
+        return ChecksumData(ct, bpc, _split(native.compute(int(ct), bpc, mv), ds))
+
+    @staticmethod
+    def _compute_list(t, bpc, ds, buffers):
+        bufs = [memoryview(b).cast("B") if not isinstance(b, (bytes, bytearray)) else memoryview(b) for b in buffers]
+        bufs = [b[:bpc] for b in bufs if len(b) > 0]  # empty elements yield nothing to iterate over
+        if not bufs:
+            return []
+        if all(len(b) == bpc for b in bufs[:-1]):
+            # the usual layout (ChunkManager.java:113-125 sizes read buffers to bpc): one pass
+            return _split(native.compute(t, bpc, b"".join(bufs)), ds)
+        # ragged elements: each is its own window -> one batched call, one descriptor per element
+        import numpy as np
+        n = len(bufs)
+        arr = (native.OzcsChunk * n)()
+        keep = []
+        outs = []
+        for i, b in enumerate(bufs):
+            a = np.frombuffer(b, dtype=np.uint8)
+            o = ctypes.create_string_buffer(ds)
+            keep.append(a)
+            outs.append(o)
+            arr[i].data = a.ctypes.data
+            arr[i].len = a.nbytes
+            arr[i].sums = ctypes.cast(o, ctypes.c_void_p).value
+            arr[i].sums_cap = ds
+            arr[i].bpc = bpc
+            arr[i].type = t
+        native.check(native.lib().ozcs_compute_batch(arr, n))
+        return [o.raw for o in outs]
+
+    @staticmethod
+    def verifyChecksum(data, checksumData, startIndex=0, isSingleByteString=None):
+        """The three verifyChecksum overloads (Checksum.java:210-290).
+
+        bytes-like data: verifyChecksum(ByteString, ChecksumData, int) / (byte[], ChecksumData).
+        list data + isSingleByteString: verifyChecksum(List<ByteString>, ChecksumData, int, boolean)."""
+        t = checksumData.getChecksumType()
+        if t == ChecksumType.NONE:
+            return True  # :241-244, :269-272
+        bpc = checksumData.getBytesPerChecksum()
+        if isinstance(data, (list, tuple)):
+            if isSingleByteString:
+                data = data[0]  # :274-277
+            else:
+                computed = Checksum(t, bpc).computeChecksum(list(data))  # :282-288
+                return checksumData.verifyChecksumDataMatches(computed, startIndex)
+        stored = checksumData.getChecksums()
+        if len(stored) == 0:
+            raise OzoneChecksumException("Original checksumData has no checksums")
+        mv = memoryview(data).cast("B") if not isinstance(data, (bytes, bytearray)) else memoryview(data)
+        if len(mv) == 0:
+            raise OzoneChecksumException("Computed checksumData has no checksums")
+        if startIndex < 0:
+            raise IndexError(startIndex)
+        # compare on the device: only the verdict comes back
+        rc, first = native.verify(int(t), bpc, mv, b"".join(stored), startIndex)
+        if rc == native.ERANGE:
+            n = (len(mv) + bpc - 1) // bpc
+            raise OzoneChecksumException(
+                "Computed checksum has %d number of checksums. Original checksum has %d number of checksums "
+                "starting from index %d" % (n, len(stored) - startIndex, startIndex))
+        if rc == native.EEMPTY:
+            raise OzoneChecksumException(native.lib().ozcs_last_error().decode())
+        if first >= 0:
+            raise OzoneChecksumException(first)
+        return True
+
+    @staticmethod
+    def getNoChecksumDataProto():
+        """Checksum.java:295-298."""
+        return ChecksumData(ChecksumType.NONE, 0).getProtoBufMessage()

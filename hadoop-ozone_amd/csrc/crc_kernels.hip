@@ -1,0 +1,326 @@
+// CRC32 / CRC32C per-window kernels for gfx950 (MI355X).
+//
+// What is computed: for every bytes-per-checksum window of every chunk, the value the reference
+// produces with reset(); update(window); getValue() (Checksum.java:66-74 over the engines of
+// ChecksumByteBufferFactory.java:74-89), stored as 4 big-endian bytes (Checksum.java:62-64), in
+// window order (Checksum.java:172-176).
+//
+// How: CDNA4 has no carry-less multiply, so the byte-serial table walk of
+// ChecksumByteBuffer.java:82-120 is replaced by its linear-algebra equivalent.
+//   * A window is cut into stripes of G KiB (G wavefronts x 64 lanes x 16 bytes).  Stripes are
+//     aligned to the END of the window, so that every stripe but the first is full and every
+//     128-bit load is naturally aligned; bytes in front of the window are masked to zero
+//     (leading zeros do not change a CRC whose register starts at 0), and the 0xFFFFFFFF initial
+//     register is folded into the first four bytes of the window.
+//   * Each lane keeps four 32-bit accumulators, one per dword of its 16-byte unit, and per stripe
+//     does  acc = (acc * x^(8*stripe) mod P) ^ dword.  The multiplication is four byte-indexed
+//     lookups.  The four tables are held in LDS in 32 interleaved copies (entry b of copy r at
+//     dword b*32 + r), so lane l always reads bank l%32: the lookups are conflict-free no matter
+//     what the data is, at one LDS lookup per input byte.
+//   * At the end of a window the accumulators are one stripe-sized message with the same CRC
+//     as the window.  It is folded with fixed shift operators: 4 slots -> lane, 64 lanes ->
+//     wavefront (prefix tree over __shfl_up), G wavefronts -> window (through LDS).  These
+//     operators use 16-entry nibble tables (conflict-free without copies: 16 consecutive banks).
+//   * The at most 15 bytes behind the last aligned 16-byte boundary are finished bit-serially.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "crc_kernels.h"
+#include "gf2_crc.h"
+
+namespace ozcs {
+
+__constant__ PolyBasis c_basis[2] = {make_poly_basis(kPolyCrc32), make_poly_basis(kPolyCrc32c)};
+
+namespace {
+
+constexpr int kThreads = 1024;
+constexpr int kWaves = kThreads / 64;
+
+// LDS layout in bytes
+constexpr uint32_t kMainBytes = 4u * 256u * 32u * 4u;          // 128 KiB: 4 byte tables x 32 copies
+constexpr int kNibOps = 14;                                    // operators 0..13 of kOpBytes
+constexpr uint32_t kNibOpBytes = 8u * 16u * 4u;                // 512 B per operator
+constexpr uint32_t kNibOff = kMainBytes;
+constexpr uint32_t kPartOff = kNibOff + kNibOps * kNibOpBytes;  // 2 x 16 partial registers
+constexpr uint32_t kLdsBytes = kPartOff + 2u * kWaves * 4u;
+
+__device__ __forceinline__ uint32_t lds_u32(const char* base, uint32_t off) {
+  return *reinterpret_cast<const uint32_t*>(base + off);
+}
+
+// x * x^(8*n) mod P through the 16-entry nibble tables of one operator.
+__device__ __forceinline__ uint32_t nib_apply(const char* op_tab, uint32_t x) {
+  uint32_t r = 0;
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    const uint32_t idx4 = (q == 0) ? ((x << 2) & 0x3cu) : ((x >> (4 * q - 2)) & 0x3cu);
+    r ^= lds_u32(op_tab, q * 64 + idx4);
+  }
+  return r;
+}
+
+struct Acc4 {
+  uint32_t a0, a1, a2, a3;
+};
+
+// Byte offsets of the four table rows an accumulator selects (row b of a table is 128 B: 32 copies).
+struct Rows4 {
+  uint32_t o0, o1, o2, o3;
+};
+__device__ __forceinline__ Rows4 rows_of(uint32_t x, uint32_t lb01, uint32_t lb23) {
+  Rows4 r;
+  r.o0 = lb01 | ((x << 7) & 0x7f80u);
+  r.o1 = lb01 | ((x >> 1) & 0x7f80u);
+  r.o2 = lb23 | ((x >> 9) & 0x7f80u);
+  r.o3 = lb23 | ((x >> 17) & 0x7f80u);
+  return r;
+}
+__device__ __forceinline__ uint32_t gather4(const char* lds, const Rows4& r, uint32_t d) {
+  const uint32_t t0 = lds_u32(lds, r.o0);
+  const uint32_t t1 = lds_u32(lds, r.o1 + 32768u);
+  const uint32_t t2 = lds_u32(lds, r.o2);
+  const uint32_t t3 = lds_u32(lds, r.o3 + 32768u);
+  return (t0 ^ t1) ^ (t2 ^ t3) ^ d;
+}
+
+// One stripe step for the lane's four accumulators: acc = acc * x^(8*stripe) ^ dword.
+// All sixteen lookups are independent; they are issued together so that one LDS round trip
+// covers the whole step.
+__device__ __forceinline__ void absorb(const char* lds, uint32_t lb01, uint32_t lb23, Acc4& a, const uint4 d) {
+  const Rows4 r0 = rows_of(a.a0, lb01, lb23), r1 = rows_of(a.a1, lb01, lb23), r2 = rows_of(a.a2, lb01, lb23),
+              r3 = rows_of(a.a3, lb01, lb23);
+  a.a0 = gather4(lds, r0, d.x);
+  a.a1 = gather4(lds, r1, d.y);
+  a.a2 = gather4(lds, r2, d.z);
+  a.a3 = gather4(lds, r3, d.w);
+}
+
+// 128-bit load through the global (not flat) address space: flat loads would tie the LDS and the
+// memory wait counters together.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) u32x4* gptr_u4;
+__device__ __forceinline__ uint4 ld16(uintptr_t p) {
+  const u32x4 v = *reinterpret_cast<gptr_u4>(p);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// Mask of the bytes of the little-endian dword at address p whose address is >= s.
+__device__ __forceinline__ uint32_t keep_from(uintptr_t p, uintptr_t s) {
+  const int64_t off = (int64_t)(s - p);
+  if (off <= 0) return 0xFFFFFFFFu;
+  if (off >= 4) return 0u;
+  return 0xFFFFFFFFu << (8 * (int)off);
+}
+
+// Folds a lane's four accumulators and then the 64 lanes of the wavefront.  The result, valid in
+// lane 63, is the register a zero-initialised CRC would hold after the 1 KiB row the 256
+// accumulators spell out.
+__device__ __forceinline__ uint32_t wave_fold(const char* nib, const Acc4& a, int lane) {
+  uint32_t b = nib_apply(nib + kOpZ16 * kNibOpBytes, a.a0) ^ nib_apply(nib + kOpZ12 * kNibOpBytes, a.a1) ^
+               nib_apply(nib + kOpZ8 * kNibOpBytes, a.a2) ^ nib_apply(nib + kOpZ4 * kNibOpBytes, a.a3);
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    uint32_t t = __shfl_up(b, 1u << i, 64);
+    t = nib_apply(nib + (kOpZ16 + i) * kNibOpBytes, t);
+    b ^= (lane >= (1 << i)) ? t : 0u;
+  }
+  return b;
+}
+
+__device__ __forceinline__ uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
+
+template <int G, int MODE>
+__global__ __launch_bounds__(kThreads) void crc_windows_kernel(const CrcLaunch p) {
+  __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
+  constexpr uint32_t kStripe = 1024u * G;
+  constexpr int kWinPerBlock = kWaves / G;  // windows a block works on at once
+  constexpr int kMainOp = kOpZ1024 + (G == 1 ? 0 : G == 2 ? 1 : G == 4 ? 2 : G == 8 ? 3 : 4);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const PolyBasis& pb = c_basis[p.poly_idx];
+
+  // ---- build the LDS tables from the 32-entry operator bases ----
+  {
+    const int j = tid >> 8, b = tid & 255;  // byte table j, entry b
+    uint32_t v = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) v ^= ((b >> i) & 1) ? pb.op[kMainOp].v[8 * j + i] : 0u;
+    uint4* dst = reinterpret_cast<uint4*>(lds + j * 32768 + b * 128);
+    const uint4 v4 = make_uint4(v, v, v, v);
+#pragma unroll
+    for (int r = 0; r < 8; r++) dst[r] = v4;
+    for (int e = tid; e < kNibOps * 128; e += kThreads) {
+      const int op = e >> 7, q = (e >> 4) & 7, nv = e & 15;
+      uint32_t w = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) w ^= ((nv >> i) & 1) ? pb.op[op].v[4 * q + i] : 0u;
+      *reinterpret_cast<uint32_t*>(lds + kNibOff + e * 4) = w;
+    }
+  }
+  __syncthreads();
+
+  const char* nib = lds + kNibOff;
+  uint32_t* part = reinterpret_cast<uint32_t*>(lds + kPartOff);
+  const uint32_t lb01 = (uint32_t)(lane & 31) * 4u;
+  const uint32_t lb23 = lb01 + 65536u;
+  const int sub = wave / G;   // which of the block's concurrent windows this wavefront works on
+  const int wsub = wave % G;  // its row inside each stripe
+
+  uint32_t it = 0;
+  for (uint64_t g0 = (uint64_t)blockIdx.x * kWinPerBlock; g0 < p.n_windows;
+       g0 += (uint64_t)gridDim.x * kWinPerBlock, it++) {
+    const uint64_t g = g0 + sub;
+    const bool valid = g < p.n_windows;
+    uintptr_t s = 0, e = 0, e16 = 0;
+    uint64_t chunk = 0, wi = 0;
+    bool vec = false;
+    uint32_t r = 0;
+    if (valid) {
+      chunk = g / p.wpc;
+      wi = g - chunk * p.wpc;
+      const uint64_t woff = wi * (uint64_t)p.bpc;
+      const uint64_t left = p.chunk_len - woff;
+      const uint64_t len = left < p.bpc ? left : p.bpc;
+      s = reinterpret_cast<uintptr_t>(p.data) + chunk * p.chunk_stride + woff;
+      e = s + len;
+      e16 = e & ~(uintptr_t)15;
+      vec = e16 >= s + 4;  // the aligned part can hold the folded initial register
+    }
+    if (vec) {
+      const uintptr_t s16 = s & ~(uintptr_t)15;
+      const uint64_t nstripes = (e16 - s16 + kStripe - 1) / kStripe;
+      uintptr_t u = e16 - nstripes * kStripe + 1024u * wsub + 16u * lane;
+      Acc4 a = {0, 0, 0, 0};
+      // first stripe: may start in front of the window; also takes the initial register
+      if (u + 16 > s) {
+        uint4 d = ld16(u);
+        const uint32_t k0 = keep_from(u, s), k1 = keep_from(u + 4, s), k2 = keep_from(u + 8, s),
+                       k3 = keep_from(u + 12, s);
+        a.a0 = (d.x & k0) ^ (k0 & ~keep_from(u, s + 4));
+        a.a1 = (d.y & k1) ^ (k1 & ~keep_from(u + 4, s + 4));
+        a.a2 = (d.z & k2) ^ (k2 & ~keep_from(u + 8, s + 4));
+        a.a3 = (d.w & k3) ^ (k3 & ~keep_from(u + 12, s + 4));
+      }
+      u += kStripe;
+      uint64_t n = nstripes - 1;  // full stripes left
+      if (n >= 4) {
+        uint4 q0 = ld16(u), q1 = ld16(u + kStripe), q2 = ld16(u + 2 * (uintptr_t)kStripe),
+              q3 = ld16(u + 3 * (uintptr_t)kStripe);
+        u += 4 * (uintptr_t)kStripe;
+        n -= 4;
+        while (n >= 4) {
+          absorb(lds, lb01, lb23, a, q0);
+          q0 = ld16(u);
+          absorb(lds, lb01, lb23, a, q1);
+          q1 = ld16(u + kStripe);
+          absorb(lds, lb01, lb23, a, q2);
+          q2 = ld16(u + 2 * (uintptr_t)kStripe);
+          absorb(lds, lb01, lb23, a, q3);
+          q3 = ld16(u + 3 * (uintptr_t)kStripe);
+          u += 4 * (uintptr_t)kStripe;
+          n -= 4;
+        }
+        absorb(lds, lb01, lb23, a, q0);
+        absorb(lds, lb01, lb23, a, q1);
+        absorb(lds, lb01, lb23, a, q2);
+        absorb(lds, lb01, lb23, a, q3);
+      }
+      for (; n > 0; n--, u += kStripe) absorb(lds, lb01, lb23, a, ld16(u));
+      r = wave_fold(nib, a, lane);
+    }
+
+    // ---- merge the G wavefronts of a window ----
+    uint32_t state;
+    if (G > 1) {
+      uint32_t* slot = part + (it & 1) * kWaves;
+      if (lane == 63) slot[wave] = r;
+      __syncthreads();
+      if (wsub != 0) continue;  // one wavefront per window finishes it (loop bounds are block-uniform)
+      uint32_t b = (lane < G) ? slot[sub * G + lane] : 0u;
+#pragma unroll
+      for (int i = 0; (1 << i) < G; i++) {
+        uint32_t t = __shfl_up(b, 1u << i, 64);
+        t = nib_apply(nib + (kOpZ1024 + i) * kNibOpBytes, t);
+        b ^= (lane >= (1 << i)) ? t : 0u;
+      }
+      state = __shfl(b, G - 1, 64);
+    } else {
+      state = __shfl(r, 63, 64);
+    }
+    if (!valid) continue;
+
+    // ---- bytes behind the last 16-byte boundary (or the whole of a tiny window), bit-serial ----
+    uintptr_t tb = e16;
+    if (!vec) {
+      state = 0xFFFFFFFFu;
+      tb = s;
+    }
+    const uint32_t poly = p.poly_idx ? kPolyCrc32c : kPolyCrc32;
+    for (; tb < e; tb++) state = crc_byte_bitwise(state, *reinterpret_cast<const __attribute__((address_space(1))) uint8_t*>(tb), poly);
+    const uint32_t be = bswap32(~state);  // getValue() then Ints.toByteArray
+
+    if (lane == 0) {
+      if (MODE == kModeCompute) {
+        uint8_t* out = p.sums + g * 4;
+        if ((reinterpret_cast<uintptr_t>(out) & 3) == 0) {
+          *reinterpret_cast<uint32_t*>(out) = be;
+        } else {
+          out[0] = (uint8_t)be; out[1] = (uint8_t)(be >> 8); out[2] = (uint8_t)(be >> 16); out[3] = (uint8_t)(be >> 24);
+        }
+      } else {
+        // ChecksumData.verifyChecksumDataMatches: stored[startIndex + i] against computed[i]
+        const uint64_t si = p.start_index + wi;
+        bool bad;
+        if (si >= p.n_expected) {
+          bad = true;
+        } else {
+          const uint8_t* ex = p.expected + chunk * p.expected_stride + si * 4;
+          uint32_t ev;
+          if ((reinterpret_cast<uintptr_t>(ex) & 3) == 0) ev = *reinterpret_cast<const uint32_t*>(ex);
+          else ev = (uint32_t)ex[0] | ((uint32_t)ex[1] << 8) | ((uint32_t)ex[2] << 16) | ((uint32_t)ex[3] << 24);
+          bad = ev != be;
+        }
+        if (bad) atomicMin(p.first_mismatch + chunk, (unsigned long long)wi);
+      }
+    }
+  }
+}
+
+template <int MODE>
+hipError_t launch_mode(const CrcLaunch& p, int group, int blocks, hipStream_t stream) {
+  switch (group) {
+    case 1: crc_windows_kernel<1, MODE><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 2: crc_windows_kernel<2, MODE><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 4: crc_windows_kernel<4, MODE><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 8: crc_windows_kernel<8, MODE><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 16: crc_windows_kernel<16, MODE><<<blocks, kThreads, 0, stream>>>(p); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace
+
+int crc_choose_group(uint64_t n_windows, uint32_t bpc, int num_cus) {
+  // Use as few wavefronts per window as still fills the chip (a fold per wavefront per window is
+  // the fixed cost), but never give a wavefront less than ~8 KiB when it can be avoided.
+  int g = 16;
+  const uint64_t want_waves = (uint64_t)num_cus * kWaves;
+  while (g > 1 && n_windows * (uint64_t)(g / 2) >= want_waves) g >>= 1;
+  while (g > 1 && (uint64_t)bpc < (uint64_t)g * 8192u) g >>= 1;
+  return g;
+}
+
+hipError_t crc_launch(const CrcLaunch& p, int mode, int group, int num_cus, hipStream_t stream) {
+  if (p.n_windows == 0) return hipSuccess;
+  const uint64_t per_block = kWaves / group;
+  uint64_t blocks = (p.n_windows + per_block - 1) / per_block;
+  if (blocks > (uint64_t)num_cus) blocks = num_cus;  // 138 KiB of LDS: one block per CU, persistent
+  return mode == kModeCompute ? launch_mode<kModeCompute>(p, group, (int)blocks, stream)
+                              : launch_mode<kModeVerify>(p, group, (int)blocks, stream);
+}
+
+}  // namespace ozcs

@@ -1,0 +1,30 @@
+// Launch interface of the SHA-256 / MD5 window kernels (digest_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ozcs {
+
+enum { kAlgoSha256 = 0, kAlgoMd5 = 1 };
+
+// Same batch layout as CrcLaunch (crc_kernels.h): chunk c at data + c*chunk_stride, wpc windows of
+// bpc bytes per chunk, the last possibly shorter; window g = c*wpc + i.
+struct DigestLaunch {
+  const uint8_t* data;
+  uint64_t chunk_len;
+  uint64_t chunk_stride;
+  uint64_t n_windows;
+  uint64_t wpc;
+  uint32_t bpc;
+  int algo;  // kAlgoSha256 (32-byte digests) or kAlgoMd5 (16-byte digests)
+  uint8_t* sums;
+  const uint8_t* expected;
+  uint64_t expected_stride;
+  uint64_t n_expected;
+  uint64_t start_index;
+  unsigned long long* first_mismatch;
+};
+
+hipError_t digest_launch(const DigestLaunch& p, int mode, hipStream_t stream);
+
+}  // namespace ozcs

@@ -1,0 +1,255 @@
+// SHA-256 / MD5 per-window kernels for gfx950 (MI355X).
+//
+// What is computed: for every bytes-per-checksum window, MessageDigest("SHA-256") or
+// MessageDigest("MD5") over the window's bytes (Checksum.java:46-60, 83-84), i.e. FIPS 180-4
+// section 6.2 / RFC 1321 section 3, digest bytes in the standard order.
+//
+// How: both hashes are Merkle-Damgard chains, so one window cannot be split; the parallelism is
+// across windows.  One lane owns one window (64 windows per wavefront, one wavefront per
+// workgroup).  Per step the wavefront fetches the next 64-byte message block of each of its 64
+// windows with coalesced 16-byte loads (four lanes per window), parks them in LDS in rows of
+// 80 bytes (64 + 16 pad: both the 128-bit stores of the loader role and the 128-bit loads of the
+// owner role are then conflict-free), and every lane runs the compression function on its own
+// block while the loads of the following block are in flight.  Padding blocks are built in
+// registers.  The kernels are integer-ALU bound, not HBM bound.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "crc_kernels.h"  // kModeCompute / kModeVerify
+#include "digest_kernels.h"
+
+namespace ozcs {
+namespace {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 u32x4_unaligned __attribute__((aligned(1)));
+typedef const __attribute__((address_space(1))) u32x4_unaligned* gptr_u4u;
+typedef const __attribute__((address_space(1))) uint8_t* gptr_u8;
+
+__device__ __forceinline__ uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+__device__ __forceinline__ uint32_t rotl(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
+
+// ------------------------------------------------------------------ SHA-256 (FIPS 180-4, 6.2.2)
+__constant__ const uint32_t kK256[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
+    0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+    0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+    0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+    0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+    0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
+    0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+
+struct Sha256 {
+  static constexpr int kWords = 8;
+  static constexpr bool kBigEndian = true;
+  static __device__ __forceinline__ void init(uint32_t* h) {
+    h[0] = 0x6a09e667; h[1] = 0xbb67ae85; h[2] = 0x3c6ef372; h[3] = 0xa54ff53a;
+    h[4] = 0x510e527f; h[5] = 0x9b05688c; h[6] = 0x1f83d9ab; h[7] = 0x5be0cd19;
+  }
+  static __device__ __forceinline__ void compress(uint32_t* h, uint32_t* w) {
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+      uint32_t wi;
+      if (i < 16) {
+        wi = w[i];
+      } else {
+        const uint32_t w15 = w[(i + 1) & 15], w2 = w[(i + 14) & 15];
+        const uint32_t s0 = rotr(w15, 7) ^ rotr(w15, 18) ^ (w15 >> 3);
+        const uint32_t s1 = rotr(w2, 17) ^ rotr(w2, 19) ^ (w2 >> 10);
+        wi = w[i & 15] = w[i & 15] + s0 + w[(i + 9) & 15] + s1;
+      }
+      const uint32_t S1 = rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25);
+      const uint32_t ch = (e & f) ^ (~e & g);
+      const uint32_t t1 = hh + S1 + ch + kK256[i] + wi;
+      const uint32_t S0 = rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22);
+      const uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
+      const uint32_t t2 = S0 + mj;
+      hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+  }
+};
+
+// ------------------------------------------------------------------ MD5 (RFC 1321, 3.4)
+__constant__ const uint32_t kKmd5[64] = {
+    0xd76aa478, 0xe8c7b756, 0x242070db, 0xc1bdceee, 0xf57c0faf, 0x4787c62a, 0xa8304613, 0xfd469501,
+    0x698098d8, 0x8b44f7af, 0xffff5bb1, 0x895cd7be, 0x6b901122, 0xfd987193, 0xa679438e, 0x49b40821,
+    0xf61e2562, 0xc040b340, 0x265e5a51, 0xe9b6c7aa, 0xd62f105d, 0x02441453, 0xd8a1e681, 0xe7d3fbc8,
+    0x21e1cde6, 0xc33707d6, 0xf4d50d87, 0x455a14ed, 0xa9e3e905, 0xfcefa3f8, 0x676f02d9, 0x8d2a4c8a,
+    0xfffa3942, 0x8771f681, 0x6d9d6122, 0xfde5380c, 0xa4beea44, 0x4bdecfa9, 0xf6bb4b60, 0xbebfbc70,
+    0x289b7ec6, 0xeaa127fa, 0xd4ef3085, 0x04881d05, 0xd9d4d039, 0xe6db99e5, 0x1fa27cf8, 0xc4ac5665,
+    0xf4292244, 0x432aff97, 0xab9423a7, 0xfc93a039, 0x655b59c3, 0x8f0ccc92, 0xffeff47d, 0x85845dd1,
+    0x6fa87e4f, 0xfe2ce6e0, 0xa3014314, 0x4e0811a1, 0xf7537e82, 0xbd3af235, 0x2ad7d2bb, 0xeb86d391};
+
+struct Md5 {
+  static constexpr int kWords = 4;
+  static constexpr bool kBigEndian = false;
+  static __device__ __forceinline__ void init(uint32_t* h) {
+    h[0] = 0x67452301; h[1] = 0xefcdab89; h[2] = 0x98badcfe; h[3] = 0x10325476;
+  }
+  static __device__ __forceinline__ void compress(uint32_t* h, uint32_t* m) {
+    constexpr int S[4][4] = {{7, 12, 17, 22}, {5, 9, 14, 20}, {4, 11, 16, 23}, {6, 10, 15, 21}};
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3];
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+      uint32_t f;
+      int g;
+      if (i < 16) { f = (b & c) | (~b & d); g = i; }
+      else if (i < 32) { f = (d & b) | (~d & c); g = (5 * i + 1) & 15; }
+      else if (i < 48) { f = b ^ c ^ d; g = (3 * i + 5) & 15; }
+      else { f = c ^ (b | ~d); g = (7 * i) & 15; }
+      const uint32_t t = d;
+      d = c;
+      c = b;
+      b = b + rotl(a + f + kKmd5[i] + m[g], S[i >> 4][i & 3]);
+      a = t;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d;
+  }
+};
+
+constexpr int kLanes = 64;
+constexpr int kRowBytes = 80;  // 64-byte block + 16 bytes of pad per window slot
+
+template <class H, int MODE>
+__global__ __launch_bounds__(kLanes) void digest_windows_kernel(const DigestLaunch p) {
+  __shared__ __attribute__((aligned(16))) char stage[kLanes * kRowBytes];
+  const int lane = threadIdx.x;
+  const uint64_t g = (uint64_t)blockIdx.x * kLanes + lane;
+  const bool valid = g < p.n_windows;
+
+  // owner role: this lane's window
+  uint64_t chunk = 0, wi = 0;
+  uint64_t start = 0;
+  uint32_t len = 0;
+  if (valid) {
+    chunk = g / p.wpc;
+    wi = g - chunk * p.wpc;
+    const uint64_t woff = wi * (uint64_t)p.bpc;
+    const uint64_t left = p.chunk_len - woff;
+    len = (uint32_t)(left < p.bpc ? left : p.bpc);
+    start = reinterpret_cast<uintptr_t>(p.data) + chunk * p.chunk_stride + woff;
+  }
+  const uint32_t nblk = valid ? (uint32_t)(((uint64_t)len + 8) / 64 + 1) : 0u;  // data + padding blocks
+
+  // loader role: for instruction i this lane fetches piece (lane & 3) of slot 16*i + (lane >> 2)
+  uint64_t lstart[4];
+  uint32_t llen[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int slot = 16 * i + (lane >> 2);
+    const uint32_t lo = __shfl((uint32_t)start, slot, 64), hi = __shfl((uint32_t)(start >> 32), slot, 64);
+    lstart[i] = ((uint64_t)hi << 32) | lo;
+    llen[i] = __shfl(len, slot, 64);
+  }
+  const uint32_t piece = (lane & 3) * 16;
+
+  auto fetch = [&](uint32_t blk, u32x4* r) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const uint64_t o = (uint64_t)blk * 64 + piece;
+      u32x4 v = {0, 0, 0, 0};
+      if (o + 16 <= llen[i]) {
+        v = *reinterpret_cast<gptr_u4u>(lstart[i] + o);
+      } else if (o < llen[i]) {  // last, partial piece of a window: byte loads, never past its end
+        uint32_t t[4] = {0, 0, 0, 0};
+        const uint32_t nb = llen[i] - (uint32_t)o;
+#pragma unroll
+        for (uint32_t k = 0; k < 15; k++)
+          if (k < nb) t[k >> 2] |= (uint32_t)(*reinterpret_cast<gptr_u8>(lstart[i] + o + k)) << (8 * (k & 3));
+        v = (u32x4){t[0], t[1], t[2], t[3]};
+      }
+      r[i] = v;
+    }
+  };
+
+  uint32_t h[H::kWords];
+  H::init(h);
+
+  u32x4 r[4];
+  fetch(0, r);
+  for (uint32_t blk = 0; __ballot(blk < nblk) != 0ull; blk++) {
+    __syncthreads();  // the previous block has been read by every owner
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      *reinterpret_cast<u32x4*>(stage + (16 * i + (lane >> 2)) * kRowBytes + piece) = r[i];
+    __syncthreads();
+    fetch(blk + 1, r);  // in flight during the compression below
+
+    uint32_t w[16];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(stage + lane * kRowBytes + 16 * j);
+      w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
+    }
+    if (H::kBigEndian) {
+#pragma unroll
+      for (int j = 0; j < 16; j++) w[j] = __builtin_bswap32(w[j]);
+    }
+    const int64_t rem = (int64_t)len - (int64_t)blk * 64;  // message bytes from this block on
+    if (rem < 64) {  // this block holds the end of the message and/or padding
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const int64_t rj = rem - 4 * j;  // message bytes in word j
+        if (rj >= 4) continue;
+        if (rj < 0) { w[j] = 0; continue; }
+        const int sh = 8 * (int)rj;
+        if (H::kBigEndian) w[j] = (rj == 0 ? 0u : (w[j] & (0xFFFFFFFFu << (32 - sh)))) | (0x80000000u >> sh);
+        else w[j] = (w[j] & ((1u << sh) - 1u)) | (0x80u << sh);
+      }
+      if (blk + 1 == nblk) {
+        const uint64_t bits = (uint64_t)len * 8;
+        if (H::kBigEndian) { w[14] = (uint32_t)(bits >> 32); w[15] = (uint32_t)bits; }
+        else { w[14] = (uint32_t)bits; w[15] = (uint32_t)(bits >> 32); }
+      }
+    }
+    if (blk < nblk) H::compress(h, w);
+  }
+  if (!valid) return;
+
+  if (H::kBigEndian) {
+#pragma unroll
+    for (int j = 0; j < H::kWords; j++) h[j] = __builtin_bswap32(h[j]);
+  }
+  constexpr int kDigest = H::kWords * 4;
+  if (MODE == kModeCompute) {
+    uint8_t* out = p.sums + g * kDigest;
+    if ((reinterpret_cast<uintptr_t>(out) & 3) == 0) {
+#pragma unroll
+      for (int j = 0; j < H::kWords; j++) reinterpret_cast<uint32_t*>(out)[j] = h[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < kDigest; j++) out[j] = (uint8_t)(h[j >> 2] >> (8 * (j & 3)));
+    }
+  } else {
+    const uint64_t si = p.start_index + wi;
+    bool bad = si >= p.n_expected;
+    if (!bad) {
+      const uint8_t* ex = p.expected + chunk * p.expected_stride + si * kDigest;
+#pragma unroll
+      for (int j = 0; j < kDigest; j++) bad |= ex[j] != (uint8_t)(h[j >> 2] >> (8 * (j & 3)));
+    }
+    if (bad) atomicMin(p.first_mismatch + chunk, (unsigned long long)wi);
+  }
+}
+
+}  // namespace
+
+hipError_t digest_launch(const DigestLaunch& p, int mode, hipStream_t stream) {
+  if (p.n_windows == 0) return hipSuccess;
+  const uint64_t blocks = (p.n_windows + kLanes - 1) / kLanes;
+  if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)blocks), block(kLanes);
+  if (p.algo == kAlgoSha256) {
+    if (mode == kModeCompute) digest_windows_kernel<Sha256, kModeCompute><<<grid, block, 0, stream>>>(p);
+    else digest_windows_kernel<Sha256, kModeVerify><<<grid, block, 0, stream>>>(p);
+  } else {
+    if (mode == kModeCompute) digest_windows_kernel<Md5, kModeCompute><<<grid, block, 0, stream>>>(p);
+    else digest_windows_kernel<Md5, kModeVerify><<<grid, block, 0, stream>>>(p);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace ozcs

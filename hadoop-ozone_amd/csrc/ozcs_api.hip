@@ -1,0 +1,465 @@
+// C ABI of the library (include/ozone_checksum.h): lifetime, the synchronous host-pointer calls,
+// the batched host call and the device-resident calls.  All compute goes to the HIP kernels; there
+// is no CPU fallback in this library -- without a usable GPU every call returns OZCS_ENODEV and the
+// caller keeps its own path (as NativeCRC32Wrapper.isAvailable() gates the reference's native CRC,
+// NativeCRC32Wrapper.java:40-42).
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <atomic>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/ozone_checksum.h"
+#include "crc_kernels.h"
+#include "digest_kernels.h"
+#include "ozcs_internal.h"
+
+namespace ozcs {
+
+thread_local std::string t_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  t_err = buf;
+  return code;
+}
+
+int fail_hip(hipError_t e, const char* what) {
+  return fail(OZCS_EHIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+Global& global() {
+  static Global g;
+  return g;
+}
+
+std::atomic<uint64_t> s_calls{0}, s_bytes{0}, s_windows{0}, s_h2d{0}, s_d2h{0}, s_launches{0};
+
+// Keeps the calling thread's current device unchanged across a call.
+DeviceGuard::DeviceGuard(int dev) : prev_(-1), ok_(false) {
+  if (hipGetDevice(&prev_) != hipSuccess) prev_ = -1;
+  ok_ = (prev_ == dev) || hipSetDevice(dev) == hipSuccess;
+}
+DeviceGuard::~DeviceGuard() {
+  if (prev_ >= 0) (void)hipSetDevice(prev_);
+}
+
+const DeviceInfo* find_device(int device) {
+  Global& g = global();
+  for (const DeviceInfo& d : g.devs)
+    if (d.id == device) return &d;
+  return nullptr;
+}
+
+int ensure_init() {
+  Global& g = global();
+  if (g.inited.load(std::memory_order_acquire)) return OZCS_OK;
+  return ozcs_init(0);
+}
+
+// ---- scratch contexts for the host-pointer calls: pooled per device, grow-only buffers ----
+
+HostCtx* acquire_ctx(int device) {
+  Global& g = global();
+  {
+    std::lock_guard<std::mutex> lk(g.mu);
+    for (size_t i = 0; i < g.free_ctx.size(); i++) {
+      if (g.free_ctx[i]->device == device) {
+        HostCtx* c = g.free_ctx[i];
+        g.free_ctx.erase(g.free_ctx.begin() + i);
+        return c;
+      }
+    }
+  }
+  HostCtx* c = new HostCtx();
+  c->device = device;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return nullptr;
+  }
+  return c;
+}
+
+void release_ctx(HostCtx* c) {
+  Global& g = global();
+  std::lock_guard<std::mutex> lk(g.mu);
+  g.free_ctx.push_back(c);
+}
+
+static void destroy_ctx(HostCtx* c) {
+  DeviceGuard dg(c->device);
+  if (c->d_data) (void)hipFree(c->d_data);
+  if (c->d_sums) (void)hipFree(c->d_sums);
+  if (c->d_aux) (void)hipFree(c->d_aux);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int ctx_reserve(void** buf, size_t* cap, size_t need) {
+  if (need <= *cap) return OZCS_OK;
+  if (*buf) (void)hipFree(*buf);
+  *buf = nullptr;
+  *cap = 0;
+  size_t want = need + need / 4;
+  want = (want + 4095) & ~(size_t)4095;
+  hipError_t e = hipMalloc(buf, want);
+  if (e != hipSuccess) {
+    e = hipMalloc(buf, need);
+    want = need;
+  }
+  if (e != hipSuccess) return fail(OZCS_ENOMEM, "hipMalloc(%zu): %s", need, hipGetErrorString(e));
+  *cap = want;
+  return OZCS_OK;
+}
+
+// ---- one launch over a uniform chunk batch, device pointers ----
+
+int launch_windows(const DeviceInfo& dev, int type, uint32_t bpc, const void* d_data, uint64_t chunk_len,
+                   uint64_t n_chunks, uint64_t chunk_stride, int mode, void* d_sums, const void* d_expected,
+                   uint64_t expected_stride, uint64_t n_expected, uint64_t start_index,
+                   unsigned long long* d_first_mismatch, hipStream_t stream) {
+  const uint64_t wpc = ozcs_num_checksums(chunk_len, bpc);
+  const uint64_t n_windows = wpc * n_chunks;
+  if (n_windows == 0) return OZCS_OK;
+  hipError_t e;
+  if (type == OZCS_CRC32 || type == OZCS_CRC32C) {
+    CrcLaunch p{};
+    p.data = static_cast<const uint8_t*>(d_data);
+    p.chunk_len = chunk_len;
+    p.chunk_stride = chunk_stride;
+    p.n_windows = n_windows;
+    p.wpc = wpc;
+    p.bpc = bpc;
+    p.poly_idx = (type == OZCS_CRC32C) ? 1 : 0;
+    p.sums = static_cast<uint8_t*>(d_sums);
+    p.expected = static_cast<const uint8_t*>(d_expected);
+    p.expected_stride = expected_stride;
+    p.n_expected = n_expected;
+    p.start_index = start_index;
+    p.first_mismatch = d_first_mismatch;
+    const int group = crc_choose_group(n_windows, bpc, dev.num_cus);
+    e = crc_launch(p, mode, group, dev.num_cus, stream);
+  } else {
+    DigestLaunch p{};
+    p.data = static_cast<const uint8_t*>(d_data);
+    p.chunk_len = chunk_len;
+    p.chunk_stride = chunk_stride;
+    p.n_windows = n_windows;
+    p.wpc = wpc;
+    p.bpc = bpc;
+    p.algo = (type == OZCS_SHA256) ? kAlgoSha256 : kAlgoMd5;
+    p.sums = static_cast<uint8_t*>(d_sums);
+    p.expected = static_cast<const uint8_t*>(d_expected);
+    p.expected_stride = expected_stride;
+    p.n_expected = n_expected;
+    p.start_index = start_index;
+    p.first_mismatch = d_first_mismatch;
+    e = digest_launch(p, mode, stream);
+  }
+  if (e != hipSuccess) return fail_hip(e, "kernel launch");
+  s_launches.fetch_add(1, std::memory_order_relaxed);
+  s_bytes.fetch_add(chunk_len * n_chunks, std::memory_order_relaxed);
+  s_windows.fetch_add(n_windows, std::memory_order_relaxed);
+  return OZCS_OK;
+}
+
+static int check_type_bpc(int type, uint32_t bpc) {
+  if (type < OZCS_NONE || type > OZCS_MD5) return fail(OZCS_EINVAL, "Unrecognized ChecksumType: %d", type);
+  if (type != OZCS_NONE && bpc == 0) return fail(OZCS_EINVAL, "bytesPerChecksum must be positive");
+  return OZCS_OK;
+}
+
+static int pick_device() {
+  Global& g = global();
+  const size_t n = g.devs.size();
+  return g.devs[g.rr.fetch_add(1, std::memory_order_relaxed) % n].id;
+}
+
+// Host-pointer compute of one chunk on one device, synchronous.
+static int compute_host_on(int device, int type, uint32_t bpc, const void* data, uint64_t len, void* sums_out,
+                           uint64_t n, size_t ds) {
+  const DeviceInfo* dev = find_device(device);
+  DeviceGuard dg(device);
+  if (!dev || !dg.ok()) return fail(OZCS_ENODEV, "device %d is not initialised", device);
+  HostCtx* c = acquire_ctx(device);
+  if (!c) return fail(OZCS_EHIP, "cannot create a stream on device %d", device);
+  int rc = ctx_reserve(&c->d_data, &c->data_cap, len);
+  if (rc == OZCS_OK) rc = ctx_reserve(&c->d_sums, &c->sums_cap, n * ds);
+  hipError_t e = hipSuccess;
+  if (rc == OZCS_OK) {
+    e = hipMemcpyAsync(c->d_data, data, len, hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) rc = fail_hip(e, "hipMemcpyAsync H2D");
+  }
+  if (rc == OZCS_OK)
+    rc = launch_windows(*dev, type, bpc, c->d_data, len, 1, len, kModeCompute, c->d_sums, nullptr, 0, 0, 0, nullptr,
+                        c->stream);
+  if (rc == OZCS_OK) {
+    e = hipMemcpyAsync(sums_out, c->d_sums, n * ds, hipMemcpyDeviceToHost, c->stream);
+    if (e != hipSuccess) rc = fail_hip(e, "hipMemcpyAsync D2H");
+  }
+  e = hipStreamSynchronize(c->stream);
+  if (rc == OZCS_OK && e != hipSuccess) rc = fail_hip(e, "hipStreamSynchronize");
+  if (rc == OZCS_OK) {
+    s_h2d.fetch_add(len, std::memory_order_relaxed);
+    s_d2h.fetch_add(n * ds, std::memory_order_relaxed);
+  }
+  release_ctx(c);
+  return rc;
+}
+
+}  // namespace ozcs
+
+using namespace ozcs;
+
+extern "C" {
+
+int ozcs_abi_version(void) { return OZCS_ABI_VERSION; }
+
+const char* ozcs_last_error(void) { return t_err.c_str(); }
+
+size_t ozcs_digest_size(int type) {
+  switch (type) {
+    case OZCS_CRC32:
+    case OZCS_CRC32C: return 4;
+    case OZCS_SHA256: return 32;
+    case OZCS_MD5: return 16;
+    default: return 0;
+  }
+}
+
+uint64_t ozcs_num_checksums(uint64_t len, uint32_t bpc) {
+  if (bpc == 0) return 0;
+  return len / bpc + (len % bpc ? 1 : 0);
+}
+
+int ozcs_init(uint32_t device_mask) {
+  Global& g = global();
+  std::lock_guard<std::mutex> lk(g.init_mu);
+  if (g.inited.load(std::memory_order_acquire)) return OZCS_OK;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    return fail(OZCS_ENODEV, "no HIP device: %s", e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+  }
+  std::vector<DeviceInfo> devs;
+  for (int i = 0; i < n && i < 32; i++) {
+    if (device_mask && !(device_mask & (1u << i))) continue;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, i) != hipSuccess) continue;
+    // The kernels are built for gfx950 only and need 138 KiB of LDS per workgroup.
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) continue;
+    DeviceInfo d;
+    d.id = i;
+    d.num_cus = prop.multiProcessorCount;
+    devs.push_back(d);
+  }
+  if (devs.empty()) return fail(OZCS_ENODEV, "no gfx950 device among %d HIP device(s)", n);
+  g.devs = devs;
+  g.inited.store(true, std::memory_order_release);
+  return OZCS_OK;
+}
+
+void ozcs_shutdown(void) {
+  Global& g = global();
+  std::lock_guard<std::mutex> lk(g.init_mu);
+  if (!g.inited.load(std::memory_order_acquire)) return;
+  std::vector<HostCtx*> ctxs;
+  {
+    std::lock_guard<std::mutex> lk2(g.mu);
+    ctxs.swap(g.free_ctx);
+  }
+  for (HostCtx* c : ctxs) destroy_ctx(c);
+  g.devs.clear();
+  g.inited.store(false, std::memory_order_release);
+}
+
+int ozcs_available(void) { return ensure_init() == OZCS_OK ? 1 : 0; }
+
+int ozcs_device_count(void) {
+  if (ensure_init() != OZCS_OK) return 0;
+  return (int)global().devs.size();
+}
+
+void ozcs_get_stats(ozcs_stats* out) {
+  if (!out) return;
+  out->calls = s_calls.load();
+  out->bytes_hashed = s_bytes.load();
+  out->windows = s_windows.load();
+  out->h2d_bytes = s_h2d.load();
+  out->d2h_bytes = s_d2h.load();
+  out->kernel_launches = s_launches.load();
+}
+
+int ozcs_compute_device(int device, int type, uint32_t bpc, const void* d_data, uint64_t chunk_len,
+                        uint64_t n_chunks, uint64_t chunk_stride, void* d_sums, uint64_t sums_cap,
+                        void* hip_stream) {
+  int rc = check_type_bpc(type, bpc);
+  if (rc != OZCS_OK) return rc;
+  if ((rc = ensure_init()) != OZCS_OK) return rc;
+  if (type == OZCS_NONE || chunk_len == 0 || n_chunks == 0) return OZCS_OK;
+  if (!d_data || !d_sums) return fail(OZCS_EINVAL, "null device pointer");
+  if (n_chunks > 1 && chunk_stride < chunk_len) return fail(OZCS_EINVAL, "chunk_stride < chunk_len");
+  const uint64_t need = ozcs_num_checksums(chunk_len, bpc) * n_chunks * ozcs_digest_size(type);
+  if (sums_cap < need) return fail(OZCS_EINVAL, "sums_cap %llu < %llu", (unsigned long long)sums_cap, (unsigned long long)need);
+  const DeviceInfo* dev = find_device(device);
+  DeviceGuard dg(device);
+  if (!dev || !dg.ok()) return fail(OZCS_ENODEV, "device %d is not initialised", device);
+  s_calls.fetch_add(1, std::memory_order_relaxed);
+  return launch_windows(*dev, type, bpc, d_data, chunk_len, n_chunks, chunk_stride, kModeCompute, d_sums, nullptr, 0,
+                        0, 0, nullptr, static_cast<hipStream_t>(hip_stream));
+}
+
+int ozcs_verify_device(int device, int type, uint32_t bpc, const void* d_data, uint64_t chunk_len,
+                       uint64_t n_chunks, uint64_t chunk_stride, const void* d_expected,
+                       uint64_t expected_stride, uint64_t n_expected, uint64_t start_index,
+                       int64_t* d_first_mismatch, void* hip_stream) {
+  int rc = check_type_bpc(type, bpc);
+  if (rc != OZCS_OK) return rc;
+  if ((rc = ensure_init()) != OZCS_OK) return rc;
+  if (!d_first_mismatch) return fail(OZCS_EINVAL, "null d_first_mismatch");
+  if (n_chunks == 0) return OZCS_OK;
+  const DeviceInfo* dev = find_device(device);
+  DeviceGuard dg(device);
+  if (!dev || !dg.ok()) return fail(OZCS_ENODEV, "device %d is not initialised", device);
+  hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+  hipError_t e = hipMemsetAsync(d_first_mismatch, 0xFF, n_chunks * sizeof(int64_t), stream);  // -1 = no mismatch
+  if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync");
+  if (type == OZCS_NONE || chunk_len == 0) return OZCS_OK;  // Checksum.java:241-244
+  if (!d_data || !d_expected) return fail(OZCS_EINVAL, "null device pointer");
+  if (n_chunks > 1 && chunk_stride < chunk_len) return fail(OZCS_EINVAL, "chunk_stride < chunk_len");
+  s_calls.fetch_add(1, std::memory_order_relaxed);
+  return launch_windows(*dev, type, bpc, d_data, chunk_len, n_chunks, chunk_stride, kModeVerify, nullptr, d_expected,
+                        expected_stride, n_expected, start_index,
+                        reinterpret_cast<unsigned long long*>(d_first_mismatch), stream);
+}
+
+int ozcs_compute(int type, uint32_t bpc, const void* data, uint64_t len, void* sums_out, uint64_t sums_cap,
+                 uint64_t* n_sums) {
+  if (n_sums) *n_sums = 0;
+  int rc = check_type_bpc(type, bpc);
+  if (rc != OZCS_OK) return rc;
+  if (type == OZCS_NONE || len == 0) return OZCS_OK;  // Checksum.java:157-160; empty buffer -> no windows
+  if (!data || !sums_out) return fail(OZCS_EINVAL, "null pointer");
+  const size_t ds = ozcs_digest_size(type);
+  const uint64_t n = ozcs_num_checksums(len, bpc);
+  if (sums_cap < n * ds) return fail(OZCS_EINVAL, "sums_cap %llu < %llu", (unsigned long long)sums_cap, (unsigned long long)(n * ds));
+  if ((rc = ensure_init()) != OZCS_OK) return rc;
+  s_calls.fetch_add(1, std::memory_order_relaxed);
+  rc = compute_host_on(pick_device(), type, bpc, data, len, sums_out, n, ds);
+  if (rc == OZCS_OK && n_sums) *n_sums = n;
+  return rc;
+}
+
+int ozcs_verify(int type, uint32_t bpc, const void* data, uint64_t len, const void* expected,
+                uint64_t n_expected, uint64_t start_index, int64_t* first_mismatch) {
+  if (first_mismatch) *first_mismatch = -1;
+  int rc = check_type_bpc(type, bpc);
+  if (rc != OZCS_OK) return rc;
+  if (type == OZCS_NONE) return OZCS_OK;  // Checksum.java:241-244
+  const size_t ds = ozcs_digest_size(type);
+  const uint64_t n = ozcs_num_checksums(len, bpc);
+  if (n_expected == 0) return fail(OZCS_EEMPTY, "Original checksumData has no checksums");  // ChecksumData.java:121-124
+  if (n == 0) return fail(OZCS_EEMPTY, "Computed checksumData has no checksums");          // ChecksumData.java:126-129
+  if (!data || !expected) return fail(OZCS_EINVAL, "null pointer");
+  if ((rc = ensure_init()) != OZCS_OK) return rc;
+  const int device = pick_device();
+  const DeviceInfo* dev = find_device(device);
+  DeviceGuard dg(device);
+  if (!dev || !dg.ok()) return fail(OZCS_ENODEV, "device %d is not initialised", device);
+  HostCtx* c = acquire_ctx(device);
+  if (!c) return fail(OZCS_EHIP, "cannot create a stream on device %d", device);
+  s_calls.fetch_add(1, std::memory_order_relaxed);
+  // only the stored digests the computed list can reach are shipped
+  const uint64_t first = start_index < n_expected ? start_index : n_expected;
+  const uint64_t avail = n_expected - first;
+  const uint64_t ship = avail < n ? avail : n;
+  rc = ctx_reserve(&c->d_data, &c->data_cap, len);
+  if (rc == OZCS_OK) rc = ctx_reserve(&c->d_sums, &c->sums_cap, (ship ? ship : 1) * ds);
+  if (rc == OZCS_OK) rc = ctx_reserve(&c->d_aux, &c->aux_cap, sizeof(int64_t));
+  hipError_t e = hipSuccess;
+  int64_t fm = -1;
+  if (rc == OZCS_OK) {
+    e = hipMemcpyAsync(c->d_data, data, len, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && ship)
+      e = hipMemcpyAsync(c->d_sums, static_cast<const uint8_t*>(expected) + first * ds, ship * ds,
+                         hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_aux, 0xFF, sizeof(int64_t), c->stream);
+    if (e != hipSuccess) rc = fail_hip(e, "hipMemcpyAsync H2D");
+  }
+  if (rc == OZCS_OK)
+    rc = launch_windows(*dev, type, bpc, c->d_data, len, 1, len, kModeVerify, nullptr, c->d_sums, 0, ship, 0,
+                        static_cast<unsigned long long*>(c->d_aux), c->stream);
+  if (rc == OZCS_OK) {
+    e = hipMemcpyAsync(&fm, c->d_aux, sizeof fm, hipMemcpyDeviceToHost, c->stream);
+    if (e != hipSuccess) rc = fail_hip(e, "hipMemcpyAsync D2H");
+  }
+  e = hipStreamSynchronize(c->stream);
+  if (rc == OZCS_OK && e != hipSuccess) rc = fail_hip(e, "hipStreamSynchronize");
+  release_ctx(c);
+  if (rc != OZCS_OK) return rc;
+  s_h2d.fetch_add(len + ship * ds, std::memory_order_relaxed);
+  s_d2h.fetch_add(sizeof fm, std::memory_order_relaxed);
+  if (fm >= 0 && (uint64_t)fm >= ship) {
+    // every reachable stored digest matched; the computed list runs past the stored one
+    return fail(OZCS_ERANGE, "Computed checksum has %llu number of checksums. Original checksum has %llu number of "
+                "checksums starting from index %llu", (unsigned long long)n, (unsigned long long)avail,
+                (unsigned long long)start_index);  // ChecksumData.java:142-147
+  }
+  if (first_mismatch) *first_mismatch = fm;
+  return OZCS_OK;
+}
+
+int ozcs_compute_batch(ozcs_chunk* chunks, uint32_t n_chunks) {
+  if (n_chunks == 0) return OZCS_OK;
+  if (!chunks) return fail(OZCS_EINVAL, "null chunk list");
+  int rc = ensure_init();
+  if (rc != OZCS_OK) {
+    for (uint32_t i = 0; i < n_chunks; i++) { chunks[i].status = rc; chunks[i].n_sums = 0; }
+    return rc;
+  }
+  Global& g = global();
+  const size_t ndev = g.devs.size();
+  auto run_range = [&](size_t d, uint32_t lo, uint32_t hi) {
+    for (uint32_t i = lo; i < hi; i++) {
+      ozcs_chunk& ch = chunks[i];
+      ch.n_sums = 0;
+      int r = check_type_bpc(ch.type, ch.bpc);
+      if (r == OZCS_OK && ch.type != OZCS_NONE && ch.len != 0) {
+        const size_t ds = ozcs_digest_size(ch.type);
+        const uint64_t n = ozcs_num_checksums(ch.len, ch.bpc);
+        if (!ch.data || !ch.sums) r = fail(OZCS_EINVAL, "null pointer in chunk %u", i);
+        else if (ch.sums_cap < n * ds) r = fail(OZCS_EINVAL, "sums_cap too small in chunk %u", i);
+        else r = compute_host_on(g.devs[d].id, ch.type, ch.bpc, ch.data, ch.len, ch.sums, n, ds);
+        if (r == OZCS_OK) ch.n_sums = n;
+      }
+      ch.status = r;
+    }
+  };
+  s_calls.fetch_add(1, std::memory_order_relaxed);
+  if (ndev == 1 || n_chunks == 1) {
+    run_range(0, 0, n_chunks);
+  } else {
+    // contiguous shards of the chunk list, one host thread per device, no inter-device traffic
+    std::vector<std::thread> th;
+    for (size_t d = 0; d < ndev; d++) {
+      const uint32_t lo = (uint32_t)((uint64_t)n_chunks * d / ndev), hi = (uint32_t)((uint64_t)n_chunks * (d + 1) / ndev);
+      if (lo < hi) th.emplace_back(run_range, d, lo, hi);
+    }
+    for (auto& t : th) t.join();
+  }
+  for (uint32_t i = 0; i < n_chunks; i++)
+    if (chunks[i].status != OZCS_OK) return chunks[i].status;
+  return OZCS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,68 @@
+// Internal state shared by the C-ABI translation units (not installed; the ABI is include/ozone_checksum.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <atomic>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace ozcs {
+
+struct DeviceInfo {
+  int id = 0;
+  int num_cus = 0;
+};
+
+// Scratch of one in-flight host-pointer call: a stream and grow-only device buffers.
+struct HostCtx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  void* d_data = nullptr;
+  size_t data_cap = 0;
+  void* d_sums = nullptr;
+  size_t sums_cap = 0;
+  void* d_aux = nullptr;
+  size_t aux_cap = 0;
+};
+
+struct Global {
+  std::mutex init_mu;
+  std::atomic<bool> inited{false};
+  std::vector<DeviceInfo> devs;
+  std::mutex mu;  // guards free_ctx
+  std::vector<HostCtx*> free_ctx;
+  std::atomic<uint64_t> rr{0};
+};
+
+Global& global();
+int ensure_init();
+const DeviceInfo* find_device(int device);
+
+class DeviceGuard {
+ public:
+  explicit DeviceGuard(int dev);
+  ~DeviceGuard();
+  bool ok() const { return ok_; }
+
+ private:
+  int prev_;
+  bool ok_;
+};
+
+int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+int fail_hip(hipError_t e, const char* what);
+
+HostCtx* acquire_ctx(int device);
+void release_ctx(HostCtx* c);
+int ctx_reserve(void** buf, size_t* cap, size_t need);
+
+int launch_windows(const DeviceInfo& dev, int type, uint32_t bpc, const void* d_data, uint64_t chunk_len,
+                   uint64_t n_chunks, uint64_t chunk_stride, int mode, void* d_sums, const void* d_expected,
+                   uint64_t expected_stride, uint64_t n_expected, uint64_t start_index,
+                   unsigned long long* d_first_mismatch, hipStream_t stream);
+
+extern std::atomic<uint64_t> s_calls, s_bytes, s_windows, s_h2d, s_d2h, s_launches;
+
+}  // namespace ozcs

@@ -1,0 +1,130 @@
+"""ctypes binding of libozcs.so -- exactly the entry points include/ozone_checksum.h declares.
+
+There is no fallback: if the library is missing or no gfx950 GPU is usable, calls raise.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libozcs.so")
+
+NONE, CRC32, CRC32C, SHA256, MD5 = 1, 2, 3, 4, 5
+OK, EINVAL, ENODEV, EHIP, ENOMEM, ERANGE, EEMPTY, EBUSY = 0, -1, -2, -3, -4, -5, -6, -7
+DIGEST_SIZE = {NONE: 0, CRC32: 4, CRC32C: 4, SHA256: 32, MD5: 16}
+
+
+class OzcsChunk(ctypes.Structure):
+    _fields_ = [("data", ctypes.c_void_p), ("len", ctypes.c_uint64), ("sums", ctypes.c_void_p),
+                ("sums_cap", ctypes.c_uint64), ("bpc", ctypes.c_uint32), ("type", ctypes.c_int32),
+                ("n_sums", ctypes.c_uint64), ("status", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class OzcsStats(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint64) for n in
+                ("calls", "bytes_hashed", "windows", "h2d_bytes", "d2h_bytes", "kernel_launches")]
+
+
+# name -> (restype, argtypes); kept in step with include/ozone_checksum.h (tests check both ways)
+SIGNATURES = {
+    "ozcs_init": (ctypes.c_int, [ctypes.c_uint32]),
+    "ozcs_shutdown": (None, []),
+    "ozcs_available": (ctypes.c_int, []),
+    "ozcs_device_count": (ctypes.c_int, []),
+    "ozcs_abi_version": (ctypes.c_int, []),
+    "ozcs_last_error": (ctypes.c_char_p, []),
+    "ozcs_digest_size": (ctypes.c_size_t, [ctypes.c_int]),
+    "ozcs_num_checksums": (ctypes.c_uint64, [ctypes.c_uint64, ctypes.c_uint32]),
+    "ozcs_compute": (ctypes.c_int, [ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64,
+                                    ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]),
+    "ozcs_verify": (ctypes.c_int, [ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64,
+                                   ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64,
+                                   ctypes.POINTER(ctypes.c_int64)]),
+    "ozcs_compute_batch": (ctypes.c_int, [ctypes.POINTER(OzcsChunk), ctypes.c_uint32]),
+    "ozcs_compute_device": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p,
+                                           ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p,
+                                           ctypes.c_uint64, ctypes.c_void_p]),
+    "ozcs_verify_device": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p,
+                                          ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p,
+                                          ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p,
+                                          ctypes.c_void_p]),
+    "ozcs_get_stats": (None, [ctypes.POINTER(OzcsStats)]),
+}
+
+
+def build(force=False):
+    """Compiles csrc/ into libozcs.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-s", "-C", CSRC, "clean"])
+    subprocess.check_call(["make", "-s", "-j8", "-C", CSRC, "libozcs.so"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("%s is missing: run __graft_entry__.build() (no CPU fallback exists)" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+class OzcsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("ozcs error %d: %s" % (code, msg))
+        self.code = code
+        self.msg = msg
+
+
+def check(rc):
+    if rc != OK:
+        raise OzcsError(rc, (lib().ozcs_last_error() or b"").decode("utf-8", "replace"))
+    return rc
+
+
+def _addr(buf):
+    """bytes / bytearray / memoryview / numpy array -> (address, nbytes, keepalive)."""
+    import numpy as np
+    if isinstance(buf, np.ndarray):
+        a = np.ascontiguousarray(buf)
+        return a.ctypes.data, a.nbytes, a
+    a = np.frombuffer(buf, dtype=np.uint8)
+    return a.ctypes.data, a.nbytes, a
+
+
+def compute(type_, bpc, data):
+    """ozcs_compute over a host buffer -> concatenated digest bytes."""
+    addr, n, keep = _addr(data)
+    ds = DIGEST_SIZE.get(type_, 0)
+    nwin = lib().ozcs_num_checksums(n, bpc)
+    out = ctypes.create_string_buffer(max(1, nwin * ds))
+    cnt = ctypes.c_uint64(0)
+    check(lib().ozcs_compute(type_, bpc, addr, n, out, nwin * ds, ctypes.byref(cnt)))
+    return out.raw[: cnt.value * ds]
+
+
+def verify(type_, bpc, data, expected, start_index=0):
+    """ozcs_verify -> (rc, first_mismatch); rc is OK / ERANGE / EEMPTY, other codes raise."""
+    addr, n, keep = _addr(data)
+    ds = DIGEST_SIZE.get(type_, 0)
+    eb = bytes(expected)
+    fm = ctypes.c_int64(-1)
+    rc = lib().ozcs_verify(type_, bpc, addr, n, eb, (len(eb) // ds) if ds else 0, start_index, ctypes.byref(fm))
+    if rc not in (OK, ERANGE, EEMPTY):
+        check(rc)
+    return rc, fm.value
+
+
+def stats():
+    s = OzcsStats()
+    lib().ozcs_get_stats(ctypes.byref(s))
+    return {n: getattr(s, n) for n, _ in OzcsStats._fields_}

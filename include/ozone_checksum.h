@@ -1,0 +1,154 @@
+/*
+ * ozone_checksum.h -- C ABI of the MI355X (gfx950) implementation of Ozone's per-chunk data
+ * checksumming: chunk buffers are cut into bytes-per-checksum windows and one CRC32 / CRC32C /
+ * SHA-256 / MD5 value is produced (or checked) per window.
+ *
+ * This is the native boundary a JNI shim binds, in the style of the reference's existing native
+ * checksum precedent NativeCRC32Wrapper (hadoop-hdds/common/src/main/java/org/apache/hadoop/util/
+ * NativeCRC32Wrapper.java:31-72): static entry points, caller-allocated outputs, an availability
+ * probe, no callbacks into the caller.  Plain pointers and sizes only.
+ *
+ * Common rules
+ *  - `type` uses the numbering of ContainerProtos.ChecksumType
+ *    (hadoop-hdds/interface-client/src/main/proto/DatanodeClientProtocol.proto:384-390).
+ *  - A buffer of `len` bytes yields ceil(len / bpc) digests, in window order, the last window
+ *    possibly shorter; 0 digests for len == 0 or type NONE (Checksum.java:155-177).
+ *  - Digest bytes: CRC32/CRC32C = 4 bytes big-endian (Checksum.java:62-64); SHA-256 = 32 bytes;
+ *    MD5 = 16 bytes.  Digests are written back to back.
+ *  - Any bpc >= 1 and any pointer alignment are accepted.
+ *  - Return value: 0 on success, a negative OZCS_E* code otherwise; ozcs_last_error() gives the
+ *    calling thread's last message.  A checksum mismatch is NOT an error code: it is reported
+ *    through first_mismatch, like the index OzoneChecksumException(int) carries
+ *    (OzoneChecksumException.java:35-37).
+ *  - Every entry point may be called from many threads at once.  Callers own their buffers; the
+ *    library owns only its device scratch, staging buffers and streams.
+ */
+#ifndef OZONE_CHECKSUM_H
+#define OZONE_CHECKSUM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OZCS_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define OZCS_API __attribute__((visibility("default")))
+#else
+#define OZCS_API
+#endif
+
+/* ContainerProtos.ChecksumType, DatanodeClientProtocol.proto:384-390 */
+enum ozcs_type {
+  OZCS_NONE = 1,
+  OZCS_CRC32 = 2,
+  OZCS_CRC32C = 3,
+  OZCS_SHA256 = 4,
+  OZCS_MD5 = 5
+};
+
+enum ozcs_status {
+  OZCS_OK = 0,
+  OZCS_EINVAL = -1,   /* unknown type (-> OzoneChecksumException(ChecksumType), Checksum.java:163-167),
+                         bpc == 0, null pointer, output capacity too small */
+  OZCS_ENODEV = -2,   /* no usable GPU: the caller keeps its CPU path (cf. NativeCRC32Wrapper.isAvailable) */
+  OZCS_EHIP = -3,     /* HIP runtime failure; message in ozcs_last_error() */
+  OZCS_ENOMEM = -4,   /* host or device allocation failed */
+  OZCS_ERANGE = -5,   /* verify: start_index + computed count exceeds the stored list
+                         (ChecksumData.java:142-147) */
+  OZCS_EEMPTY = -6,   /* verify: stored or computed list is empty (ChecksumData.java:121-129) */
+  OZCS_EBUSY = -7     /* pipeline: no free slot */
+};
+
+/* ---- lifetime (replaces the static initialiser + isAvailable() pair of NativeCRC32Wrapper.java:40-42) ---- */
+
+/* Initialises the library on the devices selected by device_mask (bit i = HIP device i; 0 = all).
+ * Idempotent and thread-safe.  Returns OZCS_ENODEV when no device is usable. */
+OZCS_API int ozcs_init(uint32_t device_mask);
+OZCS_API void ozcs_shutdown(void);
+/* 1 when ozcs_init has succeeded (calling it first if needed), else 0. */
+OZCS_API int ozcs_available(void);
+OZCS_API int ozcs_device_count(void);
+OZCS_API int ozcs_abi_version(void);
+OZCS_API const char* ozcs_last_error(void);
+
+/* 0 / 4 / 4 / 32 / 16 for NONE / CRC32 / CRC32C / SHA256 / MD5; 0 for unknown types. */
+OZCS_API size_t ozcs_digest_size(int type);
+/* ceil(len / bpc); 0 when bpc == 0. */
+OZCS_API uint64_t ozcs_num_checksums(uint64_t len, uint32_t bpc);
+
+/* ---- host-pointer, synchronous: Checksum.computeChecksum / Checksum.verifyChecksum ---- */
+
+/* Checksum.computeChecksum(ByteBuffer) (Checksum.java:140-177), shaped like
+ * NativeCRC32Wrapper.calculateChunkedSumsByteArray (NativeCRC32Wrapper.java:65-70).
+ * data/sums_out are host memory.  *n_sums receives the digest count. */
+OZCS_API int ozcs_compute(int type, uint32_t bpc, const void* data, uint64_t len,
+                 void* sums_out, uint64_t sums_cap, uint64_t* n_sums);
+
+/* Checksum.verifyChecksum(data, checksumData, startIndex) (Checksum.java:237-250) followed by
+ * ChecksumData.verifyChecksumDataMatches (ChecksumData.java:117-149), shaped like
+ * NativeCRC32Wrapper.verifyChunkedSumsByteArray (NativeCRC32Wrapper.java:52-58).
+ * `expected` holds n_expected stored digests; computed[i] is compared with expected[start_index + i].
+ * *first_mismatch = the first failing i (relative to the computed list), or -1.
+ * type NONE returns OZCS_OK without looking at the data (Checksum.java:241-244). */
+OZCS_API int ozcs_verify(int type, uint32_t bpc, const void* data, uint64_t len,
+                const void* expected, uint64_t n_expected, uint64_t start_index,
+                int64_t* first_mismatch);
+
+/* ---- host-pointer, batched: many independent chunks, mixed types allowed ---- */
+
+typedef struct ozcs_chunk {
+  const void* data;     /* in : host pointer                                   */
+  uint64_t len;         /* in                                                  */
+  void* sums;           /* in : host output buffer                             */
+  uint64_t sums_cap;    /* in : its capacity in bytes                          */
+  uint32_t bpc;         /* in                                                  */
+  int32_t type;         /* in : enum ozcs_type                                 */
+  uint64_t n_sums;      /* out: digests written                                */
+  int32_t status;       /* out: per-chunk OZCS_* code                          */
+  int32_t reserved;
+} ozcs_chunk;
+
+/* The loop of BlockOutputStream.writeChunkToContainer (BlockOutputStream.java:645-656) over many
+ * chunks at once.  Chunks are sharded contiguously over the initialised devices (chunk list, not
+ * windows); there is no inter-device traffic.  Returns the first non-OK per-chunk status, or OZCS_OK. */
+OZCS_API int ozcs_compute_batch(ozcs_chunk* chunks, uint32_t n_chunks);
+
+/* ---- device-resident: pointers are device memory on `device`, work is queued on hip_stream ----
+ * (hip_stream is a hipStream_t passed as void*; NULL = the default stream.)  No implicit
+ * synchronisation: results are valid once the stream reaches the end of the call's work. */
+
+/* n_chunks chunks of chunk_len bytes, chunk c at d_data + c*chunk_stride, each cut into windows from
+ * its own offset 0.  Digests of chunk c start at d_sums + c * ceil(chunk_len/bpc) * digest_size. */
+OZCS_API int ozcs_compute_device(int device, int type, uint32_t bpc, const void* d_data, uint64_t chunk_len,
+                        uint64_t n_chunks, uint64_t chunk_stride, void* d_sums, uint64_t sums_cap,
+                        void* hip_stream);
+
+/* Same layout; chunk c's stored list starts at d_expected + c*expected_stride and holds n_expected
+ * digests.  d_first_mismatch[c] (int64, device memory) receives the first failing window index of
+ * chunk c relative to its computed list, or -1.  An index i with start_index + i >= n_expected
+ * counts as failing (the host wrapper maps it to OZCS_ERANGE). */
+OZCS_API int ozcs_verify_device(int device, int type, uint32_t bpc, const void* d_data, uint64_t chunk_len,
+                       uint64_t n_chunks, uint64_t chunk_stride, const void* d_expected,
+                       uint64_t expected_stride, uint64_t n_expected, uint64_t start_index,
+                       int64_t* d_first_mismatch, void* hip_stream);
+
+/* ---- counters (no counterpart in the reference, which has no checksum-throughput metric) ---- */
+
+typedef struct ozcs_stats {
+  uint64_t calls;            /* entry-point calls that launched work */
+  uint64_t bytes_hashed;     /* input bytes handed to kernels        */
+  uint64_t windows;          /* digests produced or checked          */
+  uint64_t h2d_bytes;
+  uint64_t d2h_bytes;
+  uint64_t kernel_launches;
+} ozcs_stats;
+OZCS_API void ozcs_get_stats(ozcs_stats* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OZONE_CHECKSUM_H */
