@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Headline benchmark: device-resident CRC32 at 1 MiB bytes-per-checksum over a batch of 256 MiB
+blocks (4 MiB chunks), the `Checksum.computeChecksum` work of BlockOutputStream.writeChunkToContainer
+(BlockOutputStream.java:645-656) for every chunk of the batch, in one launch per step.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over the rank's whole batch, inputs already resident in HBM.
+Chunks are independent, so ranks shard the batch with no data-path collective (weak scaling: every
+rank holds `--blocks` blocks).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MIB = 1 << 20
+BLOCK_BYTES = 256 * MIB   # ozone.scm.block.size, OzoneConfigKeys.java:115-116
+CHUNK_BYTES = 4 * MIB     # ozone.scm.chunk.size / stream buffer, OzoneClientConfig.java:50-55
+HBM_PEAK_GBPS = 8000.0    # MI355X HBM3E datasheet peak
+
+
+def shard_blocks(total_blocks, rank, world):
+    """Contiguous shard [lo, hi) of a block list for `rank` of `world` (chunk-list sharding, no overlap)."""
+    lo = total_blocks * rank // world
+    hi = total_blocks * (rank + 1) // world
+    return lo, hi
+
+
+def aggregate(bytes_per_rank_step, steps, max_elapsed_s, world):
+    """Whole-job throughput in GB/s (1e9 input bytes per second) from the slowest rank's time."""
+    total = bytes_per_rank_step * steps * world
+    return total / max_elapsed_s / 1e9
+
+
+def load_profile_traffic(workload):
+    """HBM bytes per launch measured by the committed rocprofv3 PMC passes, if they cover this workload."""
+    path = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        ent = rec.get(workload)
+        return ent.get("hbm_bytes_per_launch") if ent else None
+    except (OSError, ValueError):
+        return None
+
+
+def cpu_baseline(sample, bpc):
+    """The oracle (C restatement of ChecksumByteBuffer.CrcIntTable.update, slice-by-8) timed on this
+    box's host cores over a bounded sample of the same workload.  Not the JVM."""
+    import zlib
+    import oracle
+    cores = min(16, os.cpu_count() or 1)
+    n1 = min(sample.nbytes, 1 << 30)
+    t1 = oracle.bench(oracle.CRC32, bpc, sample[:n1], threads=1, reps=2)
+    tn = oracle.bench(oracle.CRC32, bpc, sample, threads=cores, reps=3)
+    mv = memoryview(sample[: min(sample.nbytes, 256 * MIB)])
+    t0 = time.perf_counter()
+    for o in range(0, len(mv), bpc):
+        zlib.crc32(mv[o:o + bpc])
+    tz = time.perf_counter() - t0
+    return {
+        "value": round(sample.nbytes / tn / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": "port",
+        "sample": "%d MiB of the same random bytes, CRC32 at %d B windows, best of 3; C slice-by-8 "
+                  "restatement of the reference's CrcIntTable, not the JVM" % (sample.nbytes // MIB, bpc),
+        "one_core_GBps": round(n1 / t1 / 1e9, 3),
+        "zlib_crc32_one_core_GBps": round(len(mv) / tz / 1e9, 3),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--blocks", type=int, default=32, help="256 MiB blocks resident per GPU (32 = 8 GiB)")
+    ap.add_argument("--type", default="CRC32", choices=["CRC32", "CRC32C", "SHA256", "MD5"])
+    ap.add_argument("--bpc", type=int, default=MIB)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from hadoop_ozone_amd import native
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (there is no CPU path in this library)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    L = native.lib()
+    native.check(L.ozcs_init(1 << local_rank))
+    type_id = getattr(native, args.type)
+    ds = native.DIGEST_SIZE[type_id]
+
+    # synthetic batch: this rank's shard of world*blocks blocks, uniform random bytes, generated on the device
+    lo, hi = shard_blocks(args.blocks * world, rank, world)
+    nbytes = (hi - lo) * BLOCK_BYTES
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + lo)
+    data = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    step_fill = 1 << 30
+    for o in range(0, nbytes, step_fill):
+        n = min(step_fill, nbytes - o)
+        data[o:o + n].view(torch.int64).random_(generator=gen)
+    n_chunks = nbytes // CHUNK_BYTES
+    wpc = (CHUNK_BYTES + args.bpc - 1) // args.bpc
+    n_windows = n_chunks * wpc
+    sums = torch.zeros(n_windows * ds, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream()
+
+    def step():
+        native.check(L.ozcs_compute_device(local_rank, type_id, args.bpc, data.data_ptr(), CHUNK_BYTES, n_chunks,
+                                           CHUNK_BYTES, sums.data_ptr(), sums.numel(), stream.cuda_stream))
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record(stream)
+        step()
+        b.record(stream)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    avg_kernel_s = sum(kernel_ms) / len(kernel_ms) / 1e3
+
+    if rank == 0:
+        value = aggregate(nbytes, args.steps, elapsed, world)
+        alg_bytes = nbytes + n_windows * ds  # window bytes read + digest bytes written, per launch
+        achieved = alg_bytes / avg_kernel_s / 1e9
+        workload = "%s compute, %d x 256 MiB blocks per GPU (4 MiB chunks, %d B windows), device-resident" % (
+            args.type, args.blocks, args.bpc)
+        out = {
+            "metric": "device-resident checksum GB/s (%s, %s bytes/checksum)" % (
+                args.type, "1MB" if args.bpc == MIB else str(args.bpc)),
+            "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": workload, "blocks_per_gpu": args.blocks, "chunk_bytes": CHUNK_BYTES,
+                       "bytes_per_checksum": args.bpc, "windows_per_gpu": n_windows, "sharding": "by block, no collective"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "traffic": load_profile_traffic("%s-%d-%d" % (args.type, args.bpc, args.blocks)),
+                         "kernel_ms_avg": round(avg_kernel_s * 1e3, 4), "kernel_ms_min": round(min(kernel_ms), 4),
+                         "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline and args.type == "CRC32":
+            sample = data[: min(nbytes, 2 << 30)].cpu().numpy()
+            out["cpu_baseline"] = cpu_baseline(sample, args.bpc)
+        elif world == 1:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

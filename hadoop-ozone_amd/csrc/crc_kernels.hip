@@ -206,9 +206,16 @@ __global__ __launch_bounds__(kThreads) void crc_windows_kernel(const CrcLaunch p
       }
       u += kStripe;
       uint64_t n = nstripes - 1;  // full stripes left
+      // When the window starts in the last bytes of the first stripe, up to three bytes of the
+      // folded initial register belong to the first 16-byte unit of the next stripe.
+      const uint4 spill = make_uint4(~keep_from(u, s + 4), ~keep_from(u + 4, s + 4), ~keep_from(u + 8, s + 4),
+                                     ~keep_from(u + 12, s + 4));
+      bool first = true;
       if (n >= 4) {
         uint4 q0 = ld16(u), q1 = ld16(u + kStripe), q2 = ld16(u + 2 * (uintptr_t)kStripe),
               q3 = ld16(u + 3 * (uintptr_t)kStripe);
+        q0.x ^= spill.x; q0.y ^= spill.y; q0.z ^= spill.z; q0.w ^= spill.w;
+        first = false;
         u += 4 * (uintptr_t)kStripe;
         n -= 4;
         while (n >= 4) {
@@ -228,7 +235,14 @@ __global__ __launch_bounds__(kThreads) void crc_windows_kernel(const CrcLaunch p
         absorb(lds, lb01, lb23, a, q2);
         absorb(lds, lb01, lb23, a, q3);
       }
-      for (; n > 0; n--, u += kStripe) absorb(lds, lb01, lb23, a, ld16(u));
+      for (; n > 0; n--, u += kStripe) {
+        uint4 d = ld16(u);
+        if (first) {
+          d.x ^= spill.x; d.y ^= spill.y; d.z ^= spill.z; d.w ^= spill.w;
+          first = false;
+        }
+        absorb(lds, lb01, lb23, a, d);
+      }
       r = wave_fold(nib, a, lane);
     }
 

@@ -48,6 +48,7 @@ std::atomic<uint64_t> s_calls{0}, s_bytes{0}, s_windows{0}, s_h2d{0}, s_d2h{0}, 
 DeviceGuard::DeviceGuard(int dev) : prev_(-1), ok_(false) {
   if (hipGetDevice(&prev_) != hipSuccess) prev_ = -1;
   ok_ = (prev_ == dev) || hipSetDevice(dev) == hipSuccess;
+  if (!ok_) (void)hipGetLastError();  // do not leave a sticky error for the caller's own HIP code
 }
 DeviceGuard::~DeviceGuard() {
   if (prev_ >= 0) (void)hipSetDevice(prev_);
@@ -188,8 +189,9 @@ static int pick_device() {
 static int compute_host_on(int device, int type, uint32_t bpc, const void* data, uint64_t len, void* sums_out,
                            uint64_t n, size_t ds) {
   const DeviceInfo* dev = find_device(device);
+  if (!dev) return fail(OZCS_ENODEV, "device %d is not initialised", device);
   DeviceGuard dg(device);
-  if (!dev || !dg.ok()) return fail(OZCS_ENODEV, "device %d is not initialised", device);
+  if (!dg.ok()) return fail(OZCS_ENODEV, "cannot select device %d", device);
   HostCtx* c = acquire_ctx(device);
   if (!c) return fail(OZCS_EHIP, "cannot create a stream on device %d", device);
   int rc = ctx_reserve(&c->d_data, &c->data_cap, len);
@@ -312,8 +314,9 @@ int ozcs_compute_device(int device, int type, uint32_t bpc, const void* d_data, 
   const uint64_t need = ozcs_num_checksums(chunk_len, bpc) * n_chunks * ozcs_digest_size(type);
   if (sums_cap < need) return fail(OZCS_EINVAL, "sums_cap %llu < %llu", (unsigned long long)sums_cap, (unsigned long long)need);
   const DeviceInfo* dev = find_device(device);
+  if (!dev) return fail(OZCS_ENODEV, "device %d is not initialised", device);
   DeviceGuard dg(device);
-  if (!dev || !dg.ok()) return fail(OZCS_ENODEV, "device %d is not initialised", device);
+  if (!dg.ok()) return fail(OZCS_ENODEV, "cannot select device %d", device);
   s_calls.fetch_add(1, std::memory_order_relaxed);
   return launch_windows(*dev, type, bpc, d_data, chunk_len, n_chunks, chunk_stride, kModeCompute, d_sums, nullptr, 0,
                         0, 0, nullptr, static_cast<hipStream_t>(hip_stream));
@@ -329,8 +332,9 @@ int ozcs_verify_device(int device, int type, uint32_t bpc, const void* d_data, u
   if (!d_first_mismatch) return fail(OZCS_EINVAL, "null d_first_mismatch");
   if (n_chunks == 0) return OZCS_OK;
   const DeviceInfo* dev = find_device(device);
+  if (!dev) return fail(OZCS_ENODEV, "device %d is not initialised", device);
   DeviceGuard dg(device);
-  if (!dev || !dg.ok()) return fail(OZCS_ENODEV, "device %d is not initialised", device);
+  if (!dg.ok()) return fail(OZCS_ENODEV, "cannot select device %d", device);
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
   hipError_t e = hipMemsetAsync(d_first_mismatch, 0xFF, n_chunks * sizeof(int64_t), stream);  // -1 = no mismatch
   if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync");
@@ -374,8 +378,9 @@ int ozcs_verify(int type, uint32_t bpc, const void* data, uint64_t len, const vo
   if ((rc = ensure_init()) != OZCS_OK) return rc;
   const int device = pick_device();
   const DeviceInfo* dev = find_device(device);
+  if (!dev) return fail(OZCS_ENODEV, "device %d is not initialised", device);
   DeviceGuard dg(device);
-  if (!dev || !dg.ok()) return fail(OZCS_ENODEV, "device %d is not initialised", device);
+  if (!dg.ok()) return fail(OZCS_ENODEV, "cannot select device %d", device);
   HostCtx* c = acquire_ctx(device);
   if (!c) return fail(OZCS_EHIP, "cannot create a stream on device %d", device);
   s_calls.fetch_add(1, std::memory_order_relaxed);

@@ -67,6 +67,12 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
+        # PyTorch's ROCm wheel bundles its own libamdhip64.so.7; whichever copy is loaded first serves
+        # the whole process, and torch cannot see the GPU through a foreign one.  Let torch go first.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("%s is missing: run __graft_entry__.build() (no CPU fallback exists)" % LIB_PATH)
         L = ctypes.CDLL(LIB_PATH)

@@ -1,0 +1,388 @@
+"""Parity of the HIP path with the CPU oracle, through the C ABI (bit-exact: all integer/byte work).
+
+Small and medium inputs are compared digest by digest with the oracle and the committed golden vectors;
+inputs at the benchmark's size are checked through size-independent properties (sampled windows against the
+oracle, GF(2) linearity of CRC, invariance under chunk permutation, verify-after-compute round trip).
+"""
+import ctypes
+import threading
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import make_data
+
+pytestmark = pytest.mark.gpu
+
+MIB = 1 << 20
+ALL = (oracle.CRC32, oracle.CRC32C, oracle.SHA256, oracle.MD5)
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch  # before the library: both then share one HIP runtime
+    from hadoop_ozone_amd import native
+    assert torch.cuda.is_available()
+    L = native.lib()
+    native.check(L.ozcs_init(0))
+    assert L.ozcs_available() == 1 and L.ozcs_device_count() >= 1
+    torch.cuda.set_device(0)
+    return torch, native, L
+
+
+def dev_compute(gpu, t, bpc, dtensor, chunk_len, n_chunks, stride):
+    torch, native, L = gpu
+    ds = native.DIGEST_SIZE[t]
+    wpc = (chunk_len + bpc - 1) // bpc
+    sums = torch.full((max(1, wpc * n_chunks * ds),), 0xEE, dtype=torch.uint8, device=dtensor.device)
+    native.check(L.ozcs_compute_device(0, t, bpc, dtensor.data_ptr(), chunk_len, n_chunks, stride, sums.data_ptr(),
+                                       wpc * n_chunks * ds, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    return bytes(sums[: wpc * n_chunks * ds].cpu().numpy())
+
+
+def oracle_chunks(t, bpc, host, chunk_len, n_chunks, stride):
+    return b"".join(oracle.compute(t, bpc, host[c * stride: c * stride + chunk_len]) for c in range(n_chunks))
+
+
+# ------------------------------------------------------------------ golden vectors, host-pointer API
+
+def test_kat(gpu, vectors):
+    _, native, _ = gpu
+    for rec in vectors["kat"]:
+        got = native.compute(rec["type"], rec["bpc"], make_data(rec["data"]))
+        assert got.hex() == "".join(rec["sums_hex"]), rec["name"]
+
+
+def test_compute_golden(gpu, vectors):
+    _, native, _ = gpu
+    for rec in vectors["compute"]:
+        got = native.compute(rec["type"], rec["bpc"], make_data(rec["data"]))
+        assert got.hex() == "".join(rec["sums_hex"]), rec["name"]
+
+
+def test_verify_golden(gpu, vectors):
+    _, native, _ = gpu
+    code = {0: native.OK, 1: native.OK, 2: native.EEMPTY, 3: native.EEMPTY, 4: native.ERANGE}
+    for v in vectors["verify"]:
+        sd = make_data(v["stored_data"])
+        ds = native.DIGEST_SIZE[v["type"]]
+        stored = oracle.compute(v["type"], v["bpc"], sd)
+        if v["stored_count"] >= 0:
+            stored = stored[: v["stored_count"] * ds]
+        d = sd[v["data_off"]: v["data_off"] + v["data_len"]].copy()
+        for o in v["flips"]:
+            d[o] ^= 0xFF
+        rc, first = native.verify(v["type"], v["bpc"], d, stored, v["start_index"])
+        assert rc == code[v["rc"]], v["name"]
+        assert first == v["first_mismatch"], v["name"]
+        # and the oracle agrees with the fixture on the same inputs
+        assert oracle.verify(v["type"], v["bpc"], d, stored, v["start_index"]) == (v["rc"], v["first_mismatch"])
+
+
+# ------------------------------------------------------------------ device-resident API against the oracle
+
+# shapes chosen so that the CRC launcher picks 16, 8, 4, 2 and 1 wavefronts per window in turn
+CRC_SHAPES = [
+    # (n_chunks, chunk_len, stride, bpc)
+    (4, 4 * MIB, 4 * MIB, MIB),                    # 16 windows of 1 MiB: a whole workgroup per window
+    (5, 4 * MIB + 4096 + 7, 4 * MIB + 8192, MIB),  # ragged last window of every chunk, padded stride
+    (160, 256 * 1024, 256 * 1024, 65536),          # 640 windows
+    (40, MIB, MIB, 32768),                         # 1280 windows
+    (48, MIB, MIB, 16384),                         # 3072 windows of 16 KiB
+    (16, MIB + 100, MIB + 128, 2048),              # 8208 windows, one wavefront each
+    (3, 100000, 100000, 512),                      # HDFS-style 512-byte windows
+    (2, 1000, 1000, 10),                           # TestChecksum-sized windows
+    (1, 777, 777, 1),                              # one byte per checksum
+]
+
+
+@pytest.mark.parametrize("shape", CRC_SHAPES, ids=lambda s: "%dx%d@%d" % (s[0], s[1], s[3]))
+@pytest.mark.parametrize("t", [oracle.CRC32, oracle.CRC32C])
+def test_crc_device_shapes(gpu, t, shape):
+    torch, native, L = gpu
+    n_chunks, chunk_len, stride, bpc = shape
+    host = oracle.splitmix64(chunk_len * 31 + bpc + t, n_chunks * stride)
+    d = torch.from_numpy(host).cuda()
+    assert dev_compute(gpu, t, bpc, d, chunk_len, n_chunks, stride) == oracle_chunks(t, bpc, host, chunk_len, n_chunks, stride)
+
+
+@pytest.mark.parametrize("t", [oracle.SHA256, oracle.MD5])
+@pytest.mark.parametrize("shape", [(70, 3072, 3072, 2048), (3, 200000, 200064, 65536), (130, 1000, 1001, 55),
+                                   (1, 64 * 300, 64 * 300, 64), (2, 4 * MIB, 4 * MIB, MIB)],
+                         ids=lambda s: "%dx%d@%d" % (s[0], s[1], s[3]))
+def test_digest_device_shapes(gpu, t, shape):
+    torch, native, L = gpu
+    n_chunks, chunk_len, stride, bpc = shape
+    host = oracle.splitmix64(chunk_len + 7 * bpc + t, n_chunks * stride)
+    d = torch.from_numpy(host).cuda()
+    assert dev_compute(gpu, t, bpc, d, chunk_len, n_chunks, stride) == oracle_chunks(t, bpc, host, chunk_len, n_chunks, stride)
+
+
+@pytest.mark.parametrize("t", ALL)
+def test_misaligned_pointers_and_lengths(gpu, t):
+    # window starts at every residue mod 16, lengths around the 4-byte / 16-byte / 64-byte boundaries
+    torch, native, L = gpu
+    host = oracle.splitmix64(99 + t, 300000)
+    d = torch.from_numpy(host).cuda()
+    ds = native.DIGEST_SIZE[t]
+    for off in range(0, 17):
+        for n, bpc in ((1, 1), (3, 3), (4, 4), (5, 4), (19, 19), (20, 20), (21, 7), (63, 64), (64, 64), (65, 64),
+                       (1000 + off, 100), (70000 + off, 4099), (262144 + 3 * off, 65536 + off)):
+            sub = d[off: off + n]
+            got = dev_compute(gpu, t, bpc, sub, n, 1, n)
+            assert got == oracle.compute(t, bpc, host[off: off + n]), (off, n, bpc)
+            assert len(got) == ((n + bpc - 1) // bpc) * ds
+
+
+def test_unaligned_sums_pointer(gpu):
+    torch, native, L = gpu
+    host = oracle.splitmix64(5, 64 * 1024)
+    d = torch.from_numpy(host).cuda()
+    for t in ALL:
+        ds = native.DIGEST_SIZE[t]
+        n = 64 * 1024 // 4096
+        sums = torch.zeros(n * ds + 8, dtype=torch.uint8, device="cuda")
+        for o in (1, 2, 3):
+            native.check(L.ozcs_compute_device(0, t, 4096, d.data_ptr(), 64 * 1024, 1, 64 * 1024,
+                                               sums.data_ptr() + o, n * ds, torch.cuda.current_stream().cuda_stream))
+            torch.cuda.synchronize()
+            assert bytes(sums[o: o + n * ds].cpu().numpy()) == oracle.compute(t, 4096, host)
+
+
+def test_empty_none_and_capacity(gpu):
+    torch, native, L = gpu
+    d = torch.zeros(1024, dtype=torch.uint8, device="cuda")
+    s = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    assert L.ozcs_compute_device(0, native.NONE, 16, d.data_ptr(), 1024, 1, 1024, s.data_ptr(), 0, st) == native.OK
+    assert L.ozcs_compute_device(0, native.CRC32, 16, d.data_ptr(), 0, 1, 0, s.data_ptr(), 0, st) == native.OK
+    assert L.ozcs_compute_device(0, native.CRC32, 16, d.data_ptr(), 1024, 1, 1024, s.data_ptr(), 64, st) == native.EINVAL
+    assert L.ozcs_compute_device(0, 7, 16, d.data_ptr(), 1024, 1, 1024, s.data_ptr(), 64, st) == native.EINVAL
+    assert L.ozcs_compute_device(5, native.CRC32, 512, d.data_ptr(), 1024, 1, 1024, s.data_ptr(), 64, st) == native.ENODEV
+    assert native.compute(native.CRC32, 16, b"") == b""
+    assert native.compute(native.NONE, 16, b"abcdef") == b""
+
+
+# ------------------------------------------------------------------ verify on the device
+
+@pytest.mark.parametrize("t,bpc", [(oracle.CRC32C, 16384), (oracle.CRC32, MIB), (oracle.SHA256, 65536), (oracle.MD5, 4096)])
+def test_verify_device_first_mismatch_per_chunk(gpu, t, bpc):
+    torch, native, L = gpu
+    n_chunks, chunk_len = 12, 2 * MIB
+    ds = native.DIGEST_SIZE[t]
+    wpc = chunk_len // bpc
+    host = oracle.splitmix64(4242 + t, n_chunks * chunk_len)
+    d = torch.from_numpy(host).cuda()
+    stored = torch.from_numpy(np.frombuffer(dev_compute(gpu, t, bpc, d, chunk_len, n_chunks, chunk_len), dtype=np.uint8).copy()).cuda()
+    fm = torch.zeros(n_chunks, dtype=torch.int64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(start_index=0, n_expected=wpc):
+        native.check(L.ozcs_verify_device(0, t, bpc, d.data_ptr(), chunk_len, n_chunks, chunk_len, stored.data_ptr(),
+                                          wpc * ds, n_expected, start_index, fm.data_ptr(), st))
+        torch.cuda.synchronize()
+        return fm.cpu().tolist()
+
+    assert run() == [-1] * n_chunks
+    # corrupt data: chunk 3 window 1 (and a later window), chunk 7 last window, chunk 11 first byte
+    expect = [-1] * n_chunks
+    for k, (c, w) in enumerate(((3, min(1, wpc - 1)), (3, wpc - 1), (7, wpc - 1), (11, 0))):
+        d[c * chunk_len + w * bpc + 5 + k] ^= 0x10
+        expect[c] = w if expect[c] < 0 else min(expect[c], w)
+    assert run() == expect
+    # a stored list shorter than the computed one: the first unreachable index is reported
+    short = [e if 0 <= e < wpc - 1 else wpc - 1 for e in expect]
+    assert run(n_expected=wpc - 1) == short
+    # wrong start index: every chunk mismatches at 0 (ChunkInputStream.java:497-500 computes it from offsets)
+    if wpc > 2:
+        assert run(start_index=1) == [0] * n_chunks
+
+
+def test_verify_k_corrupted_windows_at_speed(gpu):
+    # config 3 shape scaled to one GPU-second of oracle work: CRC32C, 16 KiB windows, k in {0, 1, 1000}
+    torch, native, L = gpu
+    bpc, chunk_len, n_chunks = 16384, 4 * MIB, 64
+    wpc = chunk_len // bpc
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    d = torch.empty(n_chunks * chunk_len, dtype=torch.uint8, device="cuda")
+    d.view(torch.int64).random_(generator=g)
+    stored = torch.from_numpy(np.frombuffer(dev_compute(gpu, oracle.CRC32C, bpc, d, chunk_len, n_chunks, chunk_len), dtype=np.uint8).copy()).cuda()
+    # the stored sums themselves are right (sampled against the oracle)
+    hs = stored.cpu().numpy()
+    for w in (0, 1, 255, 256, 5000, n_chunks * wpc - 1):
+        win = d[w * bpc: (w + 1) * bpc].cpu().numpy()
+        assert bytes(hs[4 * w: 4 * w + 4]) == oracle.compute(oracle.CRC32C, bpc, win)
+    fm = torch.zeros(n_chunks, dtype=torch.int64, device="cuda")
+    rng = np.random.default_rng(8)
+    for k in (0, 1, 1000):
+        bad = rng.choice(n_chunks * wpc, size=k, replace=False)
+        for w in bad:
+            d[int(w) * bpc + int(rng.integers(0, bpc))] ^= 0x01
+        native.check(L.ozcs_verify_device(0, oracle.CRC32C, bpc, d.data_ptr(), chunk_len, n_chunks, chunk_len,
+                                          stored.data_ptr(), wpc * 4, wpc, 0, fm.data_ptr(),
+                                          torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        expect = [-1] * n_chunks
+        for w in bad:
+            c, i = divmod(int(w), wpc)
+            expect[c] = i if expect[c] < 0 else min(expect[c], i)
+        assert fm.cpu().tolist() == expect
+        stored = torch.from_numpy(np.frombuffer(dev_compute(gpu, oracle.CRC32C, bpc, d, chunk_len, n_chunks, chunk_len), dtype=np.uint8).copy()).cuda()
+
+
+# ------------------------------------------------------------------ benchmark-sized properties
+
+def test_full_size_properties_crc32_1mib(gpu):
+    """8 GiB of 4 MiB chunks at 1 MiB windows (BASELINE config 2 with 32 blocks)."""
+    torch, native, L = gpu
+    nbytes = 32 * 256 * MIB
+    chunk = 4 * MIB
+    g = torch.Generator(device="cuda")
+    g.manual_seed(77)
+    a = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    for o in range(0, nbytes, 1 << 30):
+        a[o: o + (1 << 30)].view(torch.int64).random_(generator=g)
+    sa = np.frombuffer(dev_compute(gpu, oracle.CRC32, MIB, a, chunk, nbytes // chunk, chunk), dtype=">u4")
+    assert sa.size == nbytes // MIB
+    # (1) sampled windows against the oracle, first/last window of the batch included
+    rng = np.random.default_rng(5)
+    for w in [0, 1, 3, 4, sa.size - 1] + rng.integers(0, sa.size, 40).tolist():
+        win = a[w * MIB: (w + 1) * MIB].cpu().numpy()
+        assert int(sa[w]) == oracle.crc32(win.tobytes()), w
+    # (2) CRC is affine over GF(2): crc(x ^ y) = crc(x) ^ crc(y) ^ crc(0...0) for equal lengths
+    half = nbytes // 2
+    x, y = a[:half], a[half:]
+    z = torch.bitwise_xor(x, y)
+    sz = np.frombuffer(dev_compute(gpu, oracle.CRC32, MIB, z, chunk, half // chunk, chunk), dtype=">u4")
+    zero = oracle.crc32(bytes(MIB))
+    nh = half // MIB
+    assert np.array_equal(sz, sa[:nh] ^ sa[nh:] ^ np.uint32(zero))
+    # (3) permuting chunks permutes their digests
+    del z
+    perm = torch.randperm(half // chunk, generator=torch.Generator().manual_seed(1))
+    xp = x.view(half // chunk, chunk)[perm.cuda()].contiguous().view(-1)
+    sp = np.frombuffer(dev_compute(gpu, oracle.CRC32, MIB, xp, chunk, half // chunk, chunk), dtype=">u4")
+    assert np.array_equal(sp.reshape(-1, 4), sa[:nh].reshape(-1, 4)[perm.numpy()])
+    del xp
+    # (4) compute -> verify round trip on the full batch, then one flipped bit is found
+    stored = torch.from_numpy(sa.view(np.uint8).copy()).cuda()
+    fm = torch.zeros(nbytes // chunk, dtype=torch.int64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    native.check(L.ozcs_verify_device(0, oracle.CRC32, MIB, a.data_ptr(), chunk, nbytes // chunk, chunk, stored.data_ptr(), 16, 4, 0, fm.data_ptr(), st))
+    torch.cuda.synchronize()
+    assert int(fm.max()) == -1 and int(fm.min()) == -1
+    a[1234 * chunk + 3 * MIB + 99] ^= 0x80
+    native.check(L.ozcs_verify_device(0, oracle.CRC32, MIB, a.data_ptr(), chunk, nbytes // chunk, chunk, stored.data_ptr(), 16, 4, 0, fm.data_ptr(), st))
+    torch.cuda.synchronize()
+    h = fm.cpu().numpy()
+    assert h[1234] == 3 and (np.delete(h, 1234) == -1).all()
+
+
+def test_sha256_md5_many_windows(gpu):
+    # lane-per-window batching at a size where every lane of many wavefronts is busy: 8192 windows of 64 KiB
+    torch, native, L = gpu
+    bpc, n = 65536, 8192
+    g = torch.Generator(device="cuda")
+    g.manual_seed(9)
+    a = torch.empty(n * bpc, dtype=torch.uint8, device="cuda")
+    a.view(torch.int64).random_(generator=g)
+    rng = np.random.default_rng(2)
+    pick = [0, 63, 64, n - 1] + rng.integers(0, n, 24).tolist()
+    for t in (oracle.SHA256, oracle.MD5):
+        ds = native.DIGEST_SIZE[t]
+        s = dev_compute(gpu, t, bpc, a, 4 * MIB, n * bpc // (4 * MIB), 4 * MIB)
+        for w in pick:
+            assert s[w * ds: (w + 1) * ds] == oracle.compute(t, bpc, a[w * bpc: (w + 1) * bpc].cpu().numpy()), (t, w)
+
+
+# ------------------------------------------------------------------ batched and concurrent host calls
+
+def test_compute_batch_mixed_types(gpu):
+    torch, native, L = gpu
+    specs = [(oracle.CRC32, MIB, 4 * MIB), (oracle.MD5, MIB, 4 * MIB), (oracle.CRC32, MIB, 4 * MIB), (oracle.CRC32, MIB, 3 * MIB + 5),
+             (oracle.SHA256, 2048, 3072), (oracle.CRC32C, 16384, 100000), (oracle.NONE, 10, 1000), (oracle.CRC32, 256, 0)]
+    n = len(specs)
+    arr = (native.OzcsChunk * n)()
+    bufs, outs = [], []
+    for i, (t, bpc, ln) in enumerate(specs):
+        b = oracle.splitmix64(100 + i, ln)
+        ds = native.DIGEST_SIZE[t]
+        o = ctypes.create_string_buffer(max(1, ((ln + bpc - 1) // bpc) * ds))
+        bufs.append(b)
+        outs.append(o)
+        arr[i].data, arr[i].len = (b.ctypes.data if ln else None), ln
+        arr[i].sums, arr[i].sums_cap = ctypes.cast(o, ctypes.c_void_p).value, len(o)
+        arr[i].bpc, arr[i].type = bpc, t
+    native.check(L.ozcs_compute_batch(arr, n))
+    for i, (t, bpc, ln) in enumerate(specs):
+        ds = native.DIGEST_SIZE[t]
+        exp = oracle.compute(t, bpc, bufs[i])
+        assert arr[i].status == native.OK and arr[i].n_sums == (len(exp) // ds if ds else 0)
+        assert outs[i].raw[: len(exp)] == exp
+    arr[1].type = 42
+    assert L.ozcs_compute_batch(arr, n) == native.EINVAL and arr[1].status == native.EINVAL and arr[0].status == native.OK
+
+
+def test_concurrent_callers(gpu):
+    # many Java threads call concurrently in the reference's deployment (one writer per BlockOutputStream)
+    torch, native, L = gpu
+    errs = []
+
+    def work(seed):
+        try:
+            for j in range(6):
+                t = ALL[(seed + j) % 4]
+                n = 50000 + 9973 * seed + j
+                d = oracle.splitmix64(seed * 100 + j, n)
+                if native.compute(t, 4096, d) != oracle.compute(t, 4096, d):
+                    errs.append((seed, j))
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(s,)) for s in range(8)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert errs == []
+
+
+# ------------------------------------------------------------------ the reference's own unit tests, through the mirror
+
+def test_reference_TestChecksum(gpu):
+    from hadoop_ozone_amd import Checksum, ChecksumData, ChecksumType, OzoneChecksumException
+    data = bytes(oracle.splitmix64(1, 55) % 26 + 97)   # RandomStringUtils.randomAlphabetic(55)
+    for t in (ChecksumType.SHA256, ChecksumType.CRC32, ChecksumType.CRC32C, ChecksumType.MD5):
+        c = Checksum(t, 10)
+        cd = c.computeChecksum(data)
+        assert len(cd.getChecksums()) == 6                     # TestChecksum.java:56-58
+        assert Checksum.verifyChecksum(data, cd) is True        # :60-61
+        bad = bytearray(data)
+        bad[50] = (bad[50] + 1) & 0xFF
+        cd2 = c.computeChecksum(bytes(bad))
+        assert cd2 != cd                                       # :67-80 testIncorrectChecksum
+        with pytest.raises(OzoneChecksumException, match="Checksum mismatch at index 5"):
+            Checksum.verifyChecksum(bytes(bad), cd)
+        assert cd == c.computeChecksum(data)                   # testChecksumMismatchForDifferentChecksumTypes' premise
+        assert cd.getChecksums() == [oracle.compute(int(t), 10, data[i:i + 10]) for i in range(0, 55, 10)]
+    a = Checksum(ChecksumType.SHA256, 10).computeChecksum(data)
+    b = Checksum(ChecksumType.CRC32, 10).computeChecksum(data)
+    assert a != b                                              # :86-101
+    # offsets (computeChecksum(byte[], off, len)) and the list overloads
+    c = Checksum(ChecksumType.CRC32, 20)
+    whole = oracle.splitmix64(2, 100).tobytes()
+    cd = c.computeChecksum(whole)
+    assert c.computeChecksum(whole, 20, 40).getChecksums() == cd.getChecksums()[1:3]
+    windows = [whole[i:i + 20] for i in range(0, 100, 20)]
+    assert c.computeChecksum(windows) == cd
+    assert Checksum.verifyChecksum(windows[1:3], cd, 1, False) is True        # ChunkInputStream.java:497-503
+    assert Checksum.verifyChecksum([whole[20:60]], cd, 1, True) is True       # V0 layout, Checksum.java:274-277
+    with pytest.raises(OzoneChecksumException, match="Checksum mismatch at index 0"):
+        Checksum.verifyChecksum(windows[1:3], cd, 2, False)
+    # ragged list: every element is one window, truncated to bpc bytes (Checksum.java:186-198)
+    rag = [whole[0:7], whole[7:40], whole[40:41]]
+    got = c.computeChecksum(rag).getChecksums()
+    assert got == [oracle.compute(oracle.CRC32, 20, r[:20]) for r in rag]
+    with pytest.raises(OzoneChecksumException, match="Computed checksum has 5 number of checksums. Original checksum has 2"):
+        Checksum.verifyChecksum(whole, ChecksumData(ChecksumType.CRC32, 20, cd.getChecksums()[:2]), 0)
