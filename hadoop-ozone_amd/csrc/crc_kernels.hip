@@ -7,23 +7,26 @@
 //
 // How: CDNA4 has no carry-less multiply, so the byte-serial table walk of
 // ChecksumByteBuffer.java:82-120 is replaced by its linear-algebra equivalent.
-//   * A window is cut into stripes of G KiB (G wavefronts x 64 lanes x 16 bytes).  Stripes are
-//     aligned to the END of the window, so that every stripe but the first is full and every
-//     128-bit load is naturally aligned; bytes in front of the window are masked to zero
-//     (leading zeros do not change a CRC whose register starts at 0), and the 0xFFFFFFFF initial
-//     register is folded into the first four bytes of the window.
-//   * Each lane keeps four 32-bit accumulators, one per dword of its 16-byte unit, and per stripe
-//     does  acc = (acc * x^(8*stripe) mod P) ^ dword.  The multiplication is four byte-indexed
-//     lookups.  The four tables are held in LDS in 32 interleaved copies (entry b of copy r at
-//     dword b*32 + r), so lane l always reads bank l%32: the lookups are conflict-free no matter
-//     what the data is, at one LDS lookup per input byte.
+//   * A window is cut into stripes of 2*G KiB: G wavefronts, each covering two 1 KiB rows
+//     (64 lanes x 16 bytes).  Stripes are aligned to the END of the window, so that every stripe
+//     but the first is full and every 128-bit load is naturally aligned; bytes in front of the
+//     window are masked to zero (leading zeros do not change a CRC whose register starts at 0),
+//     and the 0xFFFFFFFF initial register is folded into the first four bytes of the window.
+//   * Each lane keeps eight 32-bit accumulators, one per dword of its two 16-byte units, and per
+//     stripe does  acc = (acc * x^(8*stripe) mod P) ^ dword.  The multiplication is four
+//     byte-indexed lookups.  The four tables are held in LDS in 32 interleaved copies (copy r of
+//     every entry sits in bank r), so lane l always reads bank l%32: the lookups are conflict-free
+//     whatever the data is, at one LDS lookup per input byte.  The two rows give every wavefront
+//     two independent dependency chains, which keeps the LDS pipeline fed.
 //   * At the end of a window the accumulators are one stripe-sized message with the same CRC
-//     as the window.  It is folded with fixed shift operators: 4 slots -> lane, 64 lanes ->
-//     wavefront (prefix tree over __shfl_up), G wavefronts -> window (through LDS).  These
-//     operators use 16-entry nibble tables (conflict-free without copies: 16 consecutive banks).
+//     as the window.  It is folded with fixed shift operators: 4 slots -> unit, 64 lanes -> row
+//     (prefix tree over __shfl_up), 2 rows -> wavefront, G wavefronts -> window (through LDS).
+//     These operators use 16-entry nibble tables (conflict-free without copies: 16 consecutive
+//     banks).
 //   * The at most 15 bytes behind the last aligned 16-byte boundary are finished bit-serially.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "crc_kernels.h"
 #include "gf2_crc.h"
@@ -36,6 +39,7 @@ namespace {
 
 constexpr int kThreads = 1024;
 constexpr int kWaves = kThreads / 64;
+constexpr uint32_t kWaveBytes = 2048;  // bytes of a stripe one wavefront covers: two 1 KiB rows
 
 // LDS layout in bytes
 constexpr uint32_t kMainBytes = 4u * 256u * 32u * 4u;          // 128 KiB: 4 byte tables x 32 copies
@@ -64,29 +68,31 @@ struct Acc4 {
   uint32_t a0, a1, a2, a3;
 };
 
-// Byte offsets of the four table rows an accumulator selects (row b of a table is 128 B: 32 copies).
+// LDS addresses of the four table entries an accumulator selects.  Tables 0/1 share rows of 256 B
+// (entry b of table t, copy r at b*256 + t*128 + r*4) and so do tables 2/3, 64 KiB further on; with
+// byte-aligned fields the whole address is ONE v_perm_b32: byte 1 <- the selected byte of x,
+// bytes 0 and 2 <- the lane's constant (copy offset; 0 or 1 for the table pair).
 struct Rows4 {
   uint32_t o0, o1, o2, o3;
 };
 __device__ __forceinline__ Rows4 rows_of(uint32_t x, uint32_t lb01, uint32_t lb23) {
   Rows4 r;
-  r.o0 = lb01 | ((x << 7) & 0x7f80u);
-  r.o1 = lb01 | ((x >> 1) & 0x7f80u);
-  r.o2 = lb23 | ((x >> 9) & 0x7f80u);
-  r.o3 = lb23 | ((x >> 17) & 0x7f80u);
+  r.o0 = __builtin_amdgcn_perm(x, lb01, 0x0c020400u);
+  r.o1 = __builtin_amdgcn_perm(x, lb01, 0x0c020500u);
+  r.o2 = __builtin_amdgcn_perm(x, lb23, 0x0c020600u);
+  r.o3 = __builtin_amdgcn_perm(x, lb23, 0x0c020700u);
   return r;
 }
 __device__ __forceinline__ uint32_t gather4(const char* lds, const Rows4& r, uint32_t d) {
   const uint32_t t0 = lds_u32(lds, r.o0);
-  const uint32_t t1 = lds_u32(lds, r.o1 + 32768u);
+  const uint32_t t1 = lds_u32(lds, r.o1 + 128u);
   const uint32_t t2 = lds_u32(lds, r.o2);
-  const uint32_t t3 = lds_u32(lds, r.o3 + 32768u);
+  const uint32_t t3 = lds_u32(lds, r.o3 + 128u);
   return (t0 ^ t1) ^ (t2 ^ t3) ^ d;
 }
 
-// One stripe step for the lane's four accumulators: acc = acc * x^(8*stripe) ^ dword.
-// All sixteen lookups are independent; they are issued together so that one LDS round trip
-// covers the whole step.
+// One stripe step for the four accumulators of a 16-byte unit: acc = acc * x^(8*stripe) ^ dword.
+// The sixteen lookups are independent of each other.
 __device__ __forceinline__ void absorb(const char* lds, uint32_t lb01, uint32_t lb23, Acc4& a, const uint4 d) {
   const Rows4 r0 = rows_of(a.a0, lb01, lb23), r1 = rows_of(a.a1, lb01, lb23), r2 = rows_of(a.a2, lb01, lb23),
               r3 = rows_of(a.a3, lb01, lb23);
@@ -100,8 +106,13 @@ __device__ __forceinline__ void absorb(const char* lds, uint32_t lb01, uint32_t 
 // memory wait counters together.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) u32x4* gptr_u4;
+// The data is read exactly once, so it is loaded non-temporally: measured on MI355X, a pure streaming
+// read in this kernel's access pattern reaches 7.0 TB/s with nt loads against 6.2 TB/s without.
 __device__ __forceinline__ uint4 ld16(uintptr_t p) {
-  const u32x4 v = *reinterpret_cast<gptr_u4>(p);
+#ifdef OZCS_TUNE_NOLOAD  // timing-only build: no memory traffic, results are wrong on purpose
+  return make_uint4((uint32_t)p, (uint32_t)(p >> 7), (uint32_t)(p >> 13), (uint32_t)(p >> 3));
+#endif
+  const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<gptr_u4>(p));
   return make_uint4(v.x, v.y, v.z, v.w);
 }
 
@@ -113,29 +124,51 @@ __device__ __forceinline__ uint32_t keep_from(uintptr_t p, uintptr_t s) {
   return 0xFFFFFFFFu << (8 * (int)off);
 }
 
-// Folds a lane's four accumulators and then the 64 lanes of the wavefront.  The result, valid in
-// lane 63, is the register a zero-initialised CRC would hold after the 1 KiB row the 256
-// accumulators spell out.
-__device__ __forceinline__ uint32_t wave_fold(const char* nib, const Acc4& a, int lane) {
-  uint32_t b = nib_apply(nib + kOpZ16 * kNibOpBytes, a.a0) ^ nib_apply(nib + kOpZ12 * kNibOpBytes, a.a1) ^
-               nib_apply(nib + kOpZ8 * kNibOpBytes, a.a2) ^ nib_apply(nib + kOpZ4 * kNibOpBytes, a.a3);
-#pragma unroll
-  for (int i = 0; i < 6; i++) {
-    uint32_t t = __shfl_up(b, 1u << i, 64);
-    t = nib_apply(nib + (kOpZ16 + i) * kNibOpBytes, t);
-    b ^= (lane >= (1 << i)) ? t : 0u;
+// The 16-byte unit at u of a window that starts at s (u + 16 > s is not required): bytes in front
+// of s are dropped, and the 0xFFFFFFFF initial register is XORed onto bytes s .. s+3.
+__device__ __forceinline__ Acc4 first_unit(uintptr_t u, uintptr_t s) {
+  Acc4 a = {0, 0, 0, 0};
+  if (u + 16 > s) {
+    const uint4 d = ld16(u);
+    const uint32_t k0 = keep_from(u, s), k1 = keep_from(u + 4, s), k2 = keep_from(u + 8, s), k3 = keep_from(u + 12, s);
+    a.a0 = (d.x & k0) ^ (k0 & ~keep_from(u, s + 4));
+    a.a1 = (d.y & k1) ^ (k1 & ~keep_from(u + 4, s + 4));
+    a.a2 = (d.z & k2) ^ (k2 & ~keep_from(u + 8, s + 4));
+    a.a3 = (d.w & k3) ^ (k3 & ~keep_from(u + 12, s + 4));
   }
-  return b;
+  return a;
 }
 
-__device__ __forceinline__ uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
+// What a unit at u >= s still owes the folded initial register (non-zero only when s + 4 > u).
+__device__ __forceinline__ uint4 init_spill(uintptr_t u, uintptr_t s) {
+  return make_uint4(~keep_from(u, s + 4), ~keep_from(u + 4, s + 4), ~keep_from(u + 8, s + 4), ~keep_from(u + 12, s + 4));
+}
+__device__ __forceinline__ uint4 xor4(uint4 a, uint4 b) { return make_uint4(a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w); }
 
-template <int G, int MODE>
+// Folds the accumulators of a wavefront's two rows.  The result, valid in lane 63, is the register a
+// zero-initialised CRC would hold after the 2 KiB the 512 accumulators spell out.
+__device__ __forceinline__ uint32_t wave_fold(const char* nib, const Acc4& a, const Acc4& b, int lane) {
+  uint32_t x = nib_apply(nib + kOpZ16 * kNibOpBytes, a.a0) ^ nib_apply(nib + kOpZ12 * kNibOpBytes, a.a1) ^
+               nib_apply(nib + kOpZ8 * kNibOpBytes, a.a2) ^ nib_apply(nib + kOpZ4 * kNibOpBytes, a.a3);
+  uint32_t y = nib_apply(nib + kOpZ16 * kNibOpBytes, b.a0) ^ nib_apply(nib + kOpZ12 * kNibOpBytes, b.a1) ^
+               nib_apply(nib + kOpZ8 * kNibOpBytes, b.a2) ^ nib_apply(nib + kOpZ4 * kNibOpBytes, b.a3);
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    uint32_t tx = __shfl_up(x, 1u << i, 64), ty = __shfl_up(y, 1u << i, 64);
+    tx = nib_apply(nib + (kOpZ16 + i) * kNibOpBytes, tx);
+    ty = nib_apply(nib + (kOpZ16 + i) * kNibOpBytes, ty);
+    x ^= (lane >= (1 << i)) ? tx : 0u;
+    y ^= (lane >= (1 << i)) ? ty : 0u;
+  }
+  return nib_apply(nib + kOpZ1024 * kNibOpBytes, x) ^ y;
+}
+
+template <int G, int MODE, int PF>
 __global__ __launch_bounds__(kThreads) void crc_windows_kernel(const CrcLaunch p) {
   __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
-  constexpr uint32_t kStripe = 1024u * G;
+  constexpr uint32_t kStripe = kWaveBytes * G;
   constexpr int kWinPerBlock = kWaves / G;  // windows a block works on at once
-  constexpr int kMainOp = kOpZ1024 + (G == 1 ? 0 : G == 2 ? 1 : G == 4 ? 2 : G == 8 ? 3 : 4);
+  constexpr int kMainOp = kOpZ2048 + (G == 1 ? 0 : G == 2 ? 1 : G == 4 ? 2 : G == 8 ? 3 : 4);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -148,7 +181,7 @@ __global__ __launch_bounds__(kThreads) void crc_windows_kernel(const CrcLaunch p
     uint32_t v = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) v ^= ((b >> i) & 1) ? pb.op[kMainOp].v[8 * j + i] : 0u;
-    uint4* dst = reinterpret_cast<uint4*>(lds + j * 32768 + b * 128);
+    uint4* dst = reinterpret_cast<uint4*>(lds + (j >> 1) * 65536 + b * 256 + (j & 1) * 128);
     const uint4 v4 = make_uint4(v, v, v, v);
 #pragma unroll
     for (int r = 0; r < 8; r++) dst[r] = v4;
@@ -167,7 +200,7 @@ __global__ __launch_bounds__(kThreads) void crc_windows_kernel(const CrcLaunch p
   const uint32_t lb01 = (uint32_t)(lane & 31) * 4u;
   const uint32_t lb23 = lb01 + 65536u;
   const int sub = wave / G;   // which of the block's concurrent windows this wavefront works on
-  const int wsub = wave % G;  // its row inside each stripe
+  const int wsub = wave % G;  // its place inside each stripe
 
   uint32_t it = 0;
   for (uint64_t g0 = (uint64_t)blockIdx.x * kWinPerBlock; g0 < p.n_windows;
@@ -192,58 +225,54 @@ __global__ __launch_bounds__(kThreads) void crc_windows_kernel(const CrcLaunch p
     if (vec) {
       const uintptr_t s16 = s & ~(uintptr_t)15;
       const uint64_t nstripes = (e16 - s16 + kStripe - 1) / kStripe;
-      uintptr_t u = e16 - nstripes * kStripe + 1024u * wsub + 16u * lane;
-      Acc4 a = {0, 0, 0, 0};
+      uintptr_t u = e16 - nstripes * kStripe + kWaveBytes * wsub + 16u * lane;  // row A; row B is 1 KiB further
       // first stripe: may start in front of the window; also takes the initial register
-      if (u + 16 > s) {
-        uint4 d = ld16(u);
-        const uint32_t k0 = keep_from(u, s), k1 = keep_from(u + 4, s), k2 = keep_from(u + 8, s),
-                       k3 = keep_from(u + 12, s);
-        a.a0 = (d.x & k0) ^ (k0 & ~keep_from(u, s + 4));
-        a.a1 = (d.y & k1) ^ (k1 & ~keep_from(u + 4, s + 4));
-        a.a2 = (d.z & k2) ^ (k2 & ~keep_from(u + 8, s + 4));
-        a.a3 = (d.w & k3) ^ (k3 & ~keep_from(u + 12, s + 4));
-      }
+      Acc4 a = first_unit(u, s), b = first_unit(u + 1024, s);
       u += kStripe;
       uint64_t n = nstripes - 1;  // full stripes left
-      // When the window starts in the last bytes of the first stripe, up to three bytes of the
-      // folded initial register belong to the first 16-byte unit of the next stripe.
-      const uint4 spill = make_uint4(~keep_from(u, s + 4), ~keep_from(u + 4, s + 4), ~keep_from(u + 8, s + 4),
-                                     ~keep_from(u + 12, s + 4));
+      // When the window starts in the last bytes of the first stripe, up to three bytes of the folded
+      // initial register belong to the first 16-byte unit of the next stripe.
+      const uint4 spill = init_spill(u, s);
       bool first = true;
-      if (n >= 4) {
-        uint4 q0 = ld16(u), q1 = ld16(u + kStripe), q2 = ld16(u + 2 * (uintptr_t)kStripe),
-              q3 = ld16(u + 3 * (uintptr_t)kStripe);
-        q0.x ^= spill.x; q0.y ^= spill.y; q0.z ^= spill.z; q0.w ^= spill.w;
-        first = false;
-        u += 4 * (uintptr_t)kStripe;
-        n -= 4;
-        while (n >= 4) {
-          absorb(lds, lb01, lb23, a, q0);
-          q0 = ld16(u);
-          absorb(lds, lb01, lb23, a, q1);
-          q1 = ld16(u + kStripe);
-          absorb(lds, lb01, lb23, a, q2);
-          q2 = ld16(u + 2 * (uintptr_t)kStripe);
-          absorb(lds, lb01, lb23, a, q3);
-          q3 = ld16(u + 3 * (uintptr_t)kStripe);
-          u += 4 * (uintptr_t)kStripe;
-          n -= 4;
+      if (n >= PF) {  // software pipeline: PF stripes (2*PF KiB per wavefront) stay in flight
+        uint4 qa[PF], qb[PF];
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+          qa[k] = ld16(u + k * (uintptr_t)kStripe);
+          qb[k] = ld16(u + k * (uintptr_t)kStripe + 1024);
         }
-        absorb(lds, lb01, lb23, a, q0);
-        absorb(lds, lb01, lb23, a, q1);
-        absorb(lds, lb01, lb23, a, q2);
-        absorb(lds, lb01, lb23, a, q3);
+        qa[0] = xor4(qa[0], spill);
+        first = false;
+        u += PF * (uintptr_t)kStripe;
+        n -= PF;
+        while (n >= PF) {
+#pragma unroll
+          for (int k = 0; k < PF; k++) {
+            absorb(lds, lb01, lb23, a, qa[k]);
+            absorb(lds, lb01, lb23, b, qb[k]);
+            qa[k] = ld16(u + k * (uintptr_t)kStripe);
+            qb[k] = ld16(u + k * (uintptr_t)kStripe + 1024);
+          }
+          u += PF * (uintptr_t)kStripe;
+          n -= PF;
+        }
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+          absorb(lds, lb01, lb23, a, qa[k]);
+          absorb(lds, lb01, lb23, b, qb[k]);
+        }
       }
       for (; n > 0; n--, u += kStripe) {
-        uint4 d = ld16(u);
+        uint4 da = ld16(u);
+        const uint4 db = ld16(u + 1024);
         if (first) {
-          d.x ^= spill.x; d.y ^= spill.y; d.z ^= spill.z; d.w ^= spill.w;
+          da = xor4(da, spill);
           first = false;
         }
-        absorb(lds, lb01, lb23, a, d);
+        absorb(lds, lb01, lb23, a, da);
+        absorb(lds, lb01, lb23, b, db);
       }
-      r = wave_fold(nib, a, lane);
+      r = wave_fold(nib, a, b, lane);
     }
 
     // ---- merge the G wavefronts of a window ----
@@ -253,14 +282,14 @@ __global__ __launch_bounds__(kThreads) void crc_windows_kernel(const CrcLaunch p
       if (lane == 63) slot[wave] = r;
       __syncthreads();
       if (wsub != 0) continue;  // one wavefront per window finishes it (loop bounds are block-uniform)
-      uint32_t b = (lane < G) ? slot[sub * G + lane] : 0u;
+      uint32_t x = (lane < G) ? slot[sub * G + lane] : 0u;
 #pragma unroll
       for (int i = 0; (1 << i) < G; i++) {
-        uint32_t t = __shfl_up(b, 1u << i, 64);
-        t = nib_apply(nib + (kOpZ1024 + i) * kNibOpBytes, t);
-        b ^= (lane >= (1 << i)) ? t : 0u;
+        uint32_t t = __shfl_up(x, 1u << i, 64);
+        t = nib_apply(nib + (kOpZ2048 + i) * kNibOpBytes, t);
+        x ^= (lane >= (1 << i)) ? t : 0u;
       }
-      state = __shfl(b, G - 1, 64);
+      state = __shfl(x, G - 1, 64);
     } else {
       state = __shfl(r, 63, 64);
     }
@@ -273,8 +302,9 @@ __global__ __launch_bounds__(kThreads) void crc_windows_kernel(const CrcLaunch p
       tb = s;
     }
     const uint32_t poly = p.poly_idx ? kPolyCrc32c : kPolyCrc32;
-    for (; tb < e; tb++) state = crc_byte_bitwise(state, *reinterpret_cast<const __attribute__((address_space(1))) uint8_t*>(tb), poly);
-    const uint32_t be = bswap32(~state);  // getValue() then Ints.toByteArray
+    for (; tb < e; tb++)
+      state = crc_byte_bitwise(state, *reinterpret_cast<const __attribute__((address_space(1))) uint8_t*>(tb), poly);
+    const uint32_t be = __builtin_bswap32(~state);  // getValue() then Ints.toByteArray
 
     if (lane == 0) {
       if (MODE == kModeCompute) {
@@ -303,22 +333,32 @@ __global__ __launch_bounds__(kThreads) void crc_windows_kernel(const CrcLaunch p
   }
 }
 
-template <int MODE>
+template <int MODE, int PF>
 hipError_t launch_mode(const CrcLaunch& p, int group, int blocks, hipStream_t stream) {
   switch (group) {
-    case 1: crc_windows_kernel<1, MODE><<<blocks, kThreads, 0, stream>>>(p); break;
-    case 2: crc_windows_kernel<2, MODE><<<blocks, kThreads, 0, stream>>>(p); break;
-    case 4: crc_windows_kernel<4, MODE><<<blocks, kThreads, 0, stream>>>(p); break;
-    case 8: crc_windows_kernel<8, MODE><<<blocks, kThreads, 0, stream>>>(p); break;
-    case 16: crc_windows_kernel<16, MODE><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 1: crc_windows_kernel<1, MODE, PF><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 2: crc_windows_kernel<2, MODE, PF><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 4: crc_windows_kernel<4, MODE, PF><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 8: crc_windows_kernel<8, MODE, PF><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 16: crc_windows_kernel<16, MODE, PF><<<blocks, kThreads, 0, stream>>>(p); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
 
+// Tuning overrides for experiments (read once): OZCS_CRC_GROUP = 1|2|4|8|16, OZCS_CRC_PF = 1|2|3|4.
+int env_int(const char* name) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : 0;
+}
+const int g_force_group = env_int("OZCS_CRC_GROUP");
+const int g_force_pf = env_int("OZCS_CRC_PF");
+
 }  // namespace
 
 int crc_choose_group(uint64_t n_windows, uint32_t bpc, int num_cus) {
+  if (g_force_group == 1 || g_force_group == 2 || g_force_group == 4 || g_force_group == 8 || g_force_group == 16)
+    return g_force_group;
   // Use as few wavefronts per window as still fills the chip (a fold per wavefront per window is
   // the fixed cost), but never give a wavefront less than ~8 KiB when it can be avoided.
   int g = 16;
@@ -333,8 +373,22 @@ hipError_t crc_launch(const CrcLaunch& p, int mode, int group, int num_cus, hipS
   const uint64_t per_block = kWaves / group;
   uint64_t blocks = (p.n_windows + per_block - 1) / per_block;
   if (blocks > (uint64_t)num_cus) blocks = num_cus;  // 138 KiB of LDS: one block per CU, persistent
-  return mode == kModeCompute ? launch_mode<kModeCompute>(p, group, (int)blocks, stream)
-                              : launch_mode<kModeVerify>(p, group, (int)blocks, stream);
+  // Default: one stripe ahead.  Deeper prefetch measured slower on MI355X (the kernel is limited by
+  // the clock the chip holds under this LDS + HBM load, and more registers in flight cost more).
+  switch (g_force_pf) {
+    case 2:
+      return mode == kModeCompute ? launch_mode<kModeCompute, 2>(p, group, (int)blocks, stream)
+                                  : launch_mode<kModeVerify, 2>(p, group, (int)blocks, stream);
+    case 3:
+      return mode == kModeCompute ? launch_mode<kModeCompute, 3>(p, group, (int)blocks, stream)
+                                  : launch_mode<kModeVerify, 3>(p, group, (int)blocks, stream);
+    case 4:
+      return mode == kModeCompute ? launch_mode<kModeCompute, 4>(p, group, (int)blocks, stream)
+                                  : launch_mode<kModeVerify, 4>(p, group, (int)blocks, stream);
+    default:
+      return mode == kModeCompute ? launch_mode<kModeCompute, 1>(p, group, (int)blocks, stream)
+                                  : launch_mode<kModeVerify, 1>(p, group, (int)blocks, stream);
+  }
 }
 
 }  // namespace ozcs

@@ -65,13 +65,14 @@ constexpr OpBasis make_op_basis(uint64_t nbytes, uint32_t poly) {
 }
 
 // Operators the kernels need, as byte counts.  Index k <-> advance by kOpBytes[k].
-//   0..3   : 4, 8, 12, 16          merge the four 32-bit accumulators of a lane (one 16-byte unit)
-//   3..9   : 16, 32, ... 512       merge the 64 lanes of a wavefront (one 1 KiB row)
-//   9..13  : 1024 ... 8192         merge up to 16 wavefronts (one stripe)
-//   9..14  : 1024 ... 16384        the streaming operator: advance by one whole stripe
+//   0..3   : 4, 8, 12, 16          merge the four 32-bit accumulators of a 16-byte unit
+//   3..8   : 16, 32, ... 512       merge the 64 lanes of a wavefront (one 1 KiB row)
+//   9      : 1024                  merge the two rows a wavefront holds
+//   10..13 : 2048 ... 16384        merge up to 16 wavefronts (one stripe)
+//   10..14 : 2048 ... 32768        the streaming operator: advance by one whole stripe
 constexpr int kNumOps = 15;
-constexpr uint32_t kOpBytes[kNumOps] = {4, 8, 12, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 1};
-constexpr int kOpZ4 = 0, kOpZ8 = 1, kOpZ12 = 2, kOpZ16 = 3, kOpZ1024 = 9, kOpZ1 = 14;
+constexpr uint32_t kOpBytes[kNumOps] = {4, 8, 12, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768};
+constexpr int kOpZ4 = 0, kOpZ8 = 1, kOpZ12 = 2, kOpZ16 = 3, kOpZ1024 = 9, kOpZ2048 = 10;
 
 struct PolyBasis {
   OpBasis op[kNumOps];

@@ -8,7 +8,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libozcs.so")
+LIB_PATH = os.environ.get("OZCS_LIB") or os.path.join(CSRC, "libozcs.so")
 
 NONE, CRC32, CRC32C, SHA256, MD5 = 1, 2, 3, 4, 5
 OK, EINVAL, ENODEV, EHIP, ENOMEM, ERANGE, EEMPTY, EBUSY = 0, -1, -2, -3, -4, -5, -6, -7

@@ -1,0 +1,112 @@
+// Measures what a pure streaming read reaches on this GPU, in the access patterns the CRC kernel could use.
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/hbm_read_bench tools/hbm_read_bench.hip
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) u32x4* gptr;
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+// grid-stride, every lane 16 B per iteration, UNROLL loads in flight
+template <int UNROLL, bool NT>
+__global__ __launch_bounds__(256) void read_gridstride(const u32x4* p, uint64_t n16, uint32_t* out) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  u32x4 acc = {0, 0, 0, 0};
+  for (; i + (UNROLL - 1) * stride < n16; i += UNROLL * stride) {
+    u32x4 v[UNROLL];
+#pragma unroll
+    for (int k = 0; k < UNROLL; k++) v[k] = NT ? __builtin_nontemporal_load((gptr)(p + i + k * stride)) : *(gptr)(p + i + k * stride);
+#pragma unroll
+    for (int k = 0; k < UNROLL; k++) acc ^= v[k];
+  }
+  for (; i < n16; i += stride) acc ^= *(gptr)(p + i);
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = 1;
+}
+
+// the CRC kernel's pattern: 1024-thread blocks, one per CU, wave w streams its own windows of `win` bytes, 1 KiB rows
+template <int UNROLL, bool NT>
+__global__ __launch_bounds__(1024) void read_wave_windows(const uint8_t* p, uint64_t nwin, uint64_t win, uint32_t* out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  u32x4 acc = {0, 0, 0, 0};
+  for (uint64_t g = (uint64_t)blockIdx.x * 16 + wave; g < nwin; g += (uint64_t)gridDim.x * 16) {
+    const uint8_t* q = p + g * win + 16 * lane;
+    for (uint64_t o = 0; o < win; o += 1024 * UNROLL) {
+      u32x4 v[UNROLL];
+#pragma unroll
+      for (int k = 0; k < UNROLL; k++) v[k] = NT ? __builtin_nontemporal_load((gptr)(q + o + 1024 * k)) : *(gptr)(q + o + 1024 * k);
+#pragma unroll
+      for (int k = 0; k < UNROLL; k++) acc ^= v[k];
+    }
+  }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = 1;
+}
+
+// 1024-thread blocks, whole block streams one window in 16 KiB stripes
+template <int UNROLL, bool NT>
+__global__ __launch_bounds__(1024) void read_block_windows(const uint8_t* p, uint64_t nwin, uint64_t win, uint32_t* out) {
+  u32x4 acc = {0, 0, 0, 0};
+  for (uint64_t g = blockIdx.x; g < nwin; g += gridDim.x) {
+    const uint8_t* q = p + g * win + 16 * threadIdx.x;
+    for (uint64_t o = 0; o < win; o += 16384 * UNROLL) {
+      u32x4 v[UNROLL];
+#pragma unroll
+      for (int k = 0; k < UNROLL; k++) v[k] = NT ? __builtin_nontemporal_load((gptr)(q + o + 16384 * k)) : *(gptr)(q + o + 16384 * k);
+#pragma unroll
+      for (int k = 0; k < UNROLL; k++) acc ^= v[k];
+    }
+  }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = 1;
+}
+
+template <class F>
+static void timeit(const char* name, uint64_t bytes, F f) {
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  for (int i = 0; i < 3; i++) f();
+  CK(hipDeviceSynchronize());
+  float best = 1e30f, sum = 0;
+  const int reps = 10;
+  for (int i = 0; i < reps; i++) {
+    CK(hipEventRecord(a)); f(); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    if (ms < best) best = ms;
+    sum += ms;
+  }
+  printf("%-44s avg %8.1f GB/s   best %8.1f GB/s\n", name, bytes / (sum / reps) / 1e6, bytes / best / 1e6);
+  fflush(stdout);
+}
+
+int main(int argc, char** argv) {
+  const uint64_t bytes = (argc > 1 ? strtoull(argv[1], 0, 10) : 8ull) << 30;
+  uint8_t* d; uint32_t* out;
+  CK(hipMalloc(&d, bytes)); CK(hipMalloc(&out, 4));
+  CK(hipMemset(d, 0x5a, bytes));
+  // random-ish content so that nothing can be compressed or deduplicated on the way
+  std::vector<uint32_t> h(1 << 22);
+  uint32_t x = 12345;
+  for (auto& v : h) { x = x * 1664525u + 1013904223u; v = x; }
+  for (uint64_t o = 0; o < bytes; o += h.size() * 4) CK(hipMemcpy(d + o, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+  const uint64_t n16 = bytes / 16, win = 1 << 20, nwin = bytes / win;
+  const u32x4* p = (const u32x4*)d;
+  printf("buffer %llu GiB\n", (unsigned long long)(bytes >> 30));
+  timeit("gridstride 2048x256 unroll4", bytes, [&] { read_gridstride<4, false><<<2048, 256>>>(p, n16, out); });
+  timeit("gridstride 2048x256 unroll8", bytes, [&] { read_gridstride<8, false><<<2048, 256>>>(p, n16, out); });
+  timeit("gridstride 2048x256 unroll8 nt", bytes, [&] { read_gridstride<8, true><<<2048, 256>>>(p, n16, out); });
+  timeit("gridstride 4096x256 unroll4", bytes, [&] { read_gridstride<4, false><<<4096, 256>>>(p, n16, out); });
+  timeit("gridstride 1024x256 unroll8", bytes, [&] { read_gridstride<8, false><<<1024, 256>>>(p, n16, out); });
+  timeit("wave-windows 256x1024 unroll4", bytes, [&] { read_wave_windows<4, false><<<256, 1024>>>(d, nwin, win, out); });
+  timeit("wave-windows 256x1024 unroll8", bytes, [&] { read_wave_windows<8, false><<<256, 1024>>>(d, nwin, win, out); });
+  timeit("wave-windows 256x1024 unroll8 nt", bytes, [&] { read_wave_windows<8, true><<<256, 1024>>>(d, nwin, win, out); });
+  timeit("wave-windows 256x1024 unroll16", bytes, [&] { read_wave_windows<16, false><<<256, 1024>>>(d, nwin, win, out); });
+  timeit("block-windows 256x1024 unroll4", bytes, [&] { read_block_windows<4, false><<<256, 1024>>>(d, nwin, win, out); });
+  timeit("block-windows 256x1024 unroll8", bytes, [&] { read_block_windows<8, false><<<256, 1024>>>(d, nwin, win, out); });
+  timeit("block-windows 256x1024 unroll8 nt", bytes, [&] { read_block_windows<8, true><<<256, 1024>>>(d, nwin, win, out); });
+  timeit("block-windows 512x1024 unroll8", bytes, [&] { read_block_windows<8, false><<<512, 1024>>>(d, nwin, win, out); });
+  timeit("hipMemsetAsync (write only)", bytes, [&] { (void)hipMemsetAsync(d, 1, bytes, 0); });
+  return 0;
+}
