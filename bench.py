@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=32, help="256 MiB blocks resident per GPU (32 = 8 GiB)")
     ap.add_argument("--type", default="CRC32", choices=["CRC32", "CRC32C", "SHA256", "MD5"])
     ap.add_argument("--bpc", type=int, default=MIB)
+    ap.add_argument("--mode", default="compute", choices=["compute", "verify"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -123,9 +124,21 @@ def main():
     sums = torch.zeros(n_windows * ds, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream()
 
-    def step():
+    def compute_step():
         native.check(L.ozcs_compute_device(local_rank, type_id, args.bpc, data.data_ptr(), CHUNK_BYTES, n_chunks,
                                            CHUNK_BYTES, sums.data_ptr(), sums.numel(), stream.cuda_stream))
+
+    first_mismatch = torch.zeros(n_chunks, dtype=torch.int64, device=dev)
+
+    def verify_step():
+        native.check(L.ozcs_verify_device(local_rank, type_id, args.bpc, data.data_ptr(), CHUNK_BYTES, n_chunks,
+                                          CHUNK_BYTES, sums.data_ptr(), wpc * ds, wpc, 0, first_mismatch.data_ptr(),
+                                          stream.cuda_stream))
+
+    step = compute_step
+    if args.mode == "verify":  # stored sums come from the compute kernel; every window must then match
+        compute_step()
+        step = verify_step
 
     for _ in range(args.warmup):
         step()
@@ -151,10 +164,13 @@ def main():
 
     if rank == 0:
         value = aggregate(nbytes, args.steps, elapsed, world)
-        alg_bytes = nbytes + n_windows * ds  # window bytes read + digest bytes written, per launch
+        # per launch: window bytes read + digest bytes written (verify: read, plus one verdict word per chunk)
+        alg_bytes = nbytes + n_windows * ds + (n_chunks * 8 if args.mode == "verify" else 0)
+        if args.mode == "verify":
+            assert int(first_mismatch.max()) == -1 and int(first_mismatch.min()) == -1
         achieved = alg_bytes / avg_kernel_s / 1e9
-        workload = "%s compute, %d x 256 MiB blocks per GPU (4 MiB chunks, %d B windows), device-resident" % (
-            args.type, args.blocks, args.bpc)
+        workload = "%s %s, %d x 256 MiB blocks per GPU (4 MiB chunks, %d B windows), device-resident" % (
+            args.type, args.mode, args.blocks, args.bpc)
         out = {
             "metric": "device-resident checksum GB/s (%s, %s bytes/checksum)" % (
                 args.type, "1MB" if args.bpc == MIB else str(args.bpc)),
@@ -169,7 +185,7 @@ def main():
                          "kernel_ms_avg": round(avg_kernel_s * 1e3, 4), "kernel_ms_min": round(min(kernel_ms), 4),
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
-        if world == 1 and not args.no_cpu_baseline and args.type == "CRC32":
+        if world == 1 and not args.no_cpu_baseline and args.type == "CRC32" and args.mode == "compute":
             sample = data[: min(nbytes, 2 << 30)].cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(sample, args.bpc)
         elif world == 1:

@@ -146,21 +146,21 @@ __device__ __forceinline__ uint4 init_spill(uintptr_t u, uintptr_t s) {
 __device__ __forceinline__ uint4 xor4(uint4 a, uint4 b) { return make_uint4(a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w); }
 
 // Folds the accumulators of a wavefront's two rows.  The result, valid in lane 63, is the register a
-// zero-initialised CRC would hold after the 2 KiB the 512 accumulators spell out.
+// zero-initialised CRC would hold after the 2 KiB the 512 accumulators spell out.  Row A lies 1 KiB in
+// front of row B, so lane by lane A is advanced by 1 KiB and merged into B before the lanes are folded.
 __device__ __forceinline__ uint32_t wave_fold(const char* nib, const Acc4& a, const Acc4& b, int lane) {
-  uint32_t x = nib_apply(nib + kOpZ16 * kNibOpBytes, a.a0) ^ nib_apply(nib + kOpZ12 * kNibOpBytes, a.a1) ^
-               nib_apply(nib + kOpZ8 * kNibOpBytes, a.a2) ^ nib_apply(nib + kOpZ4 * kNibOpBytes, a.a3);
+  const uint32_t x = nib_apply(nib + kOpZ16 * kNibOpBytes, a.a0) ^ nib_apply(nib + kOpZ12 * kNibOpBytes, a.a1) ^
+                     nib_apply(nib + kOpZ8 * kNibOpBytes, a.a2) ^ nib_apply(nib + kOpZ4 * kNibOpBytes, a.a3);
   uint32_t y = nib_apply(nib + kOpZ16 * kNibOpBytes, b.a0) ^ nib_apply(nib + kOpZ12 * kNibOpBytes, b.a1) ^
                nib_apply(nib + kOpZ8 * kNibOpBytes, b.a2) ^ nib_apply(nib + kOpZ4 * kNibOpBytes, b.a3);
+  y ^= nib_apply(nib + kOpZ1024 * kNibOpBytes, x);
 #pragma unroll
   for (int i = 0; i < 6; i++) {
-    uint32_t tx = __shfl_up(x, 1u << i, 64), ty = __shfl_up(y, 1u << i, 64);
-    tx = nib_apply(nib + (kOpZ16 + i) * kNibOpBytes, tx);
-    ty = nib_apply(nib + (kOpZ16 + i) * kNibOpBytes, ty);
-    x ^= (lane >= (1 << i)) ? tx : 0u;
-    y ^= (lane >= (1 << i)) ? ty : 0u;
+    uint32_t t = __shfl_up(y, 1u << i, 64);
+    t = nib_apply(nib + (kOpZ16 + i) * kNibOpBytes, t);
+    y ^= (lane >= (1 << i)) ? t : 0u;
   }
-  return nib_apply(nib + kOpZ1024 * kNibOpBytes, x) ^ y;
+  return y;
 }
 
 template <int G, int MODE, int PF>
