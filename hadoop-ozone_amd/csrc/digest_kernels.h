@@ -27,4 +27,21 @@ struct DigestLaunch {
 
 hipError_t digest_launch(const DigestLaunch& p, int mode, hipStream_t stream);
 
+// Unrelated chunks hashed by one launch (compute only); the list travels in the kernel arguments.
+constexpr int kMaxDigestJobs = 96;
+struct DigestJob {
+  const uint8_t* data;  // device pointer of the chunk
+  uint64_t len;
+  uint8_t* sums;        // device pointer of its digests
+  uint32_t bpc;
+  uint32_t first_window;  // index of the chunk's first window in the launch
+};
+struct DigestJobList {
+  DigestJob jobs[kMaxDigestJobs];
+  uint32_t n_jobs;
+  uint32_t n_windows;
+  int algo;
+};
+hipError_t digest_launch_jobs(const DigestJobList& p, hipStream_t stream);
+
 }  // namespace ozcs

@@ -113,25 +113,10 @@ struct Md5 {
 constexpr int kLanes = 64;
 constexpr int kRowBytes = 80;  // 64-byte block + 16 bytes of pad per window slot
 
-template <class H, int MODE>
-__global__ __launch_bounds__(kLanes) void digest_windows_kernel(const DigestLaunch p) {
-  __shared__ __attribute__((aligned(16))) char stage[kLanes * kRowBytes];
-  const int lane = threadIdx.x;
-  const uint64_t g = (uint64_t)blockIdx.x * kLanes + lane;
-  const bool valid = g < p.n_windows;
-
-  // owner role: this lane's window
-  uint64_t chunk = 0, wi = 0;
-  uint64_t start = 0;
-  uint32_t len = 0;
-  if (valid) {
-    chunk = g / p.wpc;
-    wi = g - chunk * p.wpc;
-    const uint64_t woff = wi * (uint64_t)p.bpc;
-    const uint64_t left = p.chunk_len - woff;
-    len = (uint32_t)(left < p.bpc ? left : p.bpc);
-    start = reinterpret_cast<uintptr_t>(p.data) + chunk * p.chunk_stride + woff;
-  }
+// Hashes this lane's window [start, start+len) (nothing when !valid); h receives the digest words in
+// output byte order.  Must be called by all 64 lanes of the one-wavefront workgroup together.
+template <class H>
+__device__ __forceinline__ void digest_core(char* stage, int lane, bool valid, uint64_t start, uint32_t len, uint32_t* h) {
   const uint32_t nblk = valid ? (uint32_t)(((uint64_t)len + 8) / 64 + 1) : 0u;  // data + padding blocks
 
   // loader role: for instruction i this lane fetches piece (lane & 3) of slot 16*i + (lane >> 2)
@@ -142,7 +127,7 @@ __global__ __launch_bounds__(kLanes) void digest_windows_kernel(const DigestLaun
     const int slot = 16 * i + (lane >> 2);
     const uint32_t lo = __shfl((uint32_t)start, slot, 64), hi = __shfl((uint32_t)(start >> 32), slot, 64);
     lstart[i] = ((uint64_t)hi << 32) | lo;
-    llen[i] = __shfl(len, slot, 64);
+    llen[i] = __shfl(valid ? len : 0u, slot, 64);
   }
   const uint32_t piece = (lane & 3) * 16;
 
@@ -165,7 +150,6 @@ __global__ __launch_bounds__(kLanes) void digest_windows_kernel(const DigestLaun
     }
   };
 
-  uint32_t h[H::kWords];
   H::init(h);
 
   u32x4 r[4];
@@ -207,22 +191,47 @@ __global__ __launch_bounds__(kLanes) void digest_windows_kernel(const DigestLaun
     }
     if (blk < nblk) H::compress(h, w);
   }
-  if (!valid) return;
-
   if (H::kBigEndian) {
 #pragma unroll
     for (int j = 0; j < H::kWords; j++) h[j] = __builtin_bswap32(h[j]);
   }
+}
+
+template <class H>
+__device__ __forceinline__ void store_digest(uint8_t* out, const uint32_t* h) {
+  constexpr int kDigest = H::kWords * 4;
+  if ((reinterpret_cast<uintptr_t>(out) & 3) == 0) {
+#pragma unroll
+    for (int j = 0; j < H::kWords; j++) reinterpret_cast<uint32_t*>(out)[j] = h[j];
+  } else {
+#pragma unroll
+    for (int j = 0; j < kDigest; j++) out[j] = (uint8_t)(h[j >> 2] >> (8 * (j & 3)));
+  }
+}
+
+// Uniform batch: chunk c at data + c*chunk_stride, wpc windows per chunk.
+template <class H, int MODE>
+__global__ __launch_bounds__(kLanes) void digest_windows_kernel(const DigestLaunch p) {
+  __shared__ __attribute__((aligned(16))) char stage[kLanes * kRowBytes];
+  const int lane = threadIdx.x;
+  const uint64_t g = (uint64_t)blockIdx.x * kLanes + lane;
+  const bool valid = g < p.n_windows;
+  uint64_t chunk = 0, wi = 0, start = 0;
+  uint32_t len = 0;
+  if (valid) {
+    chunk = g / p.wpc;
+    wi = g - chunk * p.wpc;
+    const uint64_t woff = wi * (uint64_t)p.bpc;
+    const uint64_t left = p.chunk_len - woff;
+    len = (uint32_t)(left < p.bpc ? left : p.bpc);
+    start = reinterpret_cast<uintptr_t>(p.data) + chunk * p.chunk_stride + woff;
+  }
+  uint32_t h[H::kWords];
+  digest_core<H>(stage, lane, valid, start, len, h);
+  if (!valid) return;
   constexpr int kDigest = H::kWords * 4;
   if (MODE == kModeCompute) {
-    uint8_t* out = p.sums + g * kDigest;
-    if ((reinterpret_cast<uintptr_t>(out) & 3) == 0) {
-#pragma unroll
-      for (int j = 0; j < H::kWords; j++) reinterpret_cast<uint32_t*>(out)[j] = h[j];
-    } else {
-#pragma unroll
-      for (int j = 0; j < kDigest; j++) out[j] = (uint8_t)(h[j >> 2] >> (8 * (j & 3)));
-    }
+    store_digest<H>(p.sums + g * kDigest, h);
   } else {
     const uint64_t si = p.start_index + wi;
     bool bad = si >= p.n_expected;
@@ -233,6 +242,33 @@ __global__ __launch_bounds__(kLanes) void digest_windows_kernel(const DigestLaun
     }
     if (bad) atomicMin(p.first_mismatch + chunk, (unsigned long long)wi);
   }
+}
+
+// Job list: up to kMaxDigestJobs unrelated chunks (own pointer, length, window size, output) in one launch,
+// so that a handful of windows per chunk still adds up to full wavefronts.
+template <class H>
+__global__ __launch_bounds__(kLanes) void digest_jobs_kernel(const DigestJobList p) {
+  __shared__ __attribute__((aligned(16))) char stage[kLanes * kRowBytes];
+  const int lane = threadIdx.x;
+  const uint32_t g = blockIdx.x * kLanes + lane;
+  const bool valid = g < p.n_windows;
+  uint64_t start = 0;
+  uint32_t len = 0;
+  uint8_t* out = nullptr;
+  if (valid) {
+    uint32_t j = 0;
+    while (j + 1 < p.n_jobs && p.jobs[j + 1].first_window <= g) j++;
+    const DigestJob& job = p.jobs[j];
+    const uint64_t wi = g - job.first_window;
+    const uint64_t woff = wi * (uint64_t)job.bpc;
+    const uint64_t left = job.len - woff;
+    len = (uint32_t)(left < job.bpc ? left : job.bpc);
+    start = reinterpret_cast<uintptr_t>(job.data) + woff;
+    out = job.sums + wi * (H::kWords * 4);
+  }
+  uint32_t h[H::kWords];
+  digest_core<H>(stage, lane, valid, start, len, h);
+  if (valid) store_digest<H>(out, h);
 }
 
 }  // namespace
@@ -249,6 +285,14 @@ hipError_t digest_launch(const DigestLaunch& p, int mode, hipStream_t stream) {
     if (mode == kModeCompute) digest_windows_kernel<Md5, kModeCompute><<<grid, block, 0, stream>>>(p);
     else digest_windows_kernel<Md5, kModeVerify><<<grid, block, 0, stream>>>(p);
   }
+  return hipGetLastError();
+}
+
+hipError_t digest_launch_jobs(const DigestJobList& p, hipStream_t stream) {
+  if (p.n_windows == 0 || p.n_jobs == 0) return hipSuccess;
+  const dim3 grid((p.n_windows + kLanes - 1) / kLanes), block(kLanes);
+  if (p.algo == kAlgoSha256) digest_jobs_kernel<Sha256><<<grid, block, 0, stream>>>(p);
+  else digest_jobs_kernel<Md5><<<grid, block, 0, stream>>>(p);
   return hipGetLastError();
 }
 

@@ -218,6 +218,108 @@ static int compute_host_on(int device, int type, uint32_t bpc, const void* data,
   return rc;
 }
 
+// One device's share [lo, hi) of a chunk list: the chunks are staged into one device buffer in groups of
+// at most kBatchStageBytes, CRC chunks are launched one by one (each launch already fills the chip for a
+// 4 MiB chunk), SHA-256 / MD5 chunks go through the job-list kernel so that their few windows per chunk
+// add up to full wavefronts.  Per-chunk status and n_sums are filled in.
+constexpr uint64_t kBatchStageBytes = 512ull << 20;
+
+static void batch_on_device(int device, ozcs_chunk* chunks, uint32_t lo, uint32_t hi) {
+  auto fail_all = [&](uint32_t a, uint32_t b, int code) {
+    for (uint32_t i = a; i < b; i++) { chunks[i].status = code; chunks[i].n_sums = 0; }
+  };
+  const DeviceInfo* dev = find_device(device);
+  if (!dev) return fail_all(lo, hi, fail(OZCS_ENODEV, "device %d is not initialised", device));
+  DeviceGuard dg(device);
+  if (!dg.ok()) return fail_all(lo, hi, fail(OZCS_ENODEV, "cannot select device %d", device));
+  HostCtx* c = acquire_ctx(device);
+  if (!c) return fail_all(lo, hi, fail(OZCS_EHIP, "cannot create a stream on device %d", device));
+  struct Item { uint32_t idx; uint64_t data_off, sums_off, n; size_t ds; };
+  uint32_t i = lo;
+  while (i < hi) {
+    // ---- pick a group that fits the staging budget, validating as we go ----
+    std::vector<Item> items;
+    uint64_t data_bytes = 0, sums_bytes = 0;
+    uint32_t j = i;
+    for (; j < hi; j++) {
+      ozcs_chunk& ch = chunks[j];
+      ch.n_sums = 0;
+      ch.status = check_type_bpc(ch.type, ch.bpc);
+      if (ch.status != OZCS_OK || ch.type == OZCS_NONE || ch.len == 0) continue;
+      const size_t ds = ozcs_digest_size(ch.type);
+      const uint64_t n = ozcs_num_checksums(ch.len, ch.bpc);
+      if (!ch.data || !ch.sums) { ch.status = fail(OZCS_EINVAL, "null pointer in chunk %u", j); continue; }
+      if (ch.sums_cap < n * ds) { ch.status = fail(OZCS_EINVAL, "sums_cap too small in chunk %u", j); continue; }
+      if (!items.empty() && data_bytes + ch.len > kBatchStageBytes) break;
+      items.push_back(Item{j, data_bytes, sums_bytes, n, ds});
+      data_bytes += (ch.len + 255) & ~(uint64_t)255;
+      sums_bytes += (n * ds + 255) & ~(uint64_t)255;
+    }
+    const uint32_t group_end = j;
+    if (!items.empty()) {
+      int rc = ctx_reserve(&c->d_data, &c->data_cap, data_bytes);
+      if (rc == OZCS_OK) rc = ctx_reserve(&c->d_sums, &c->sums_cap, sums_bytes);
+      hipError_t e = hipSuccess;
+      uint8_t* dd = static_cast<uint8_t*>(c->d_data);
+      uint8_t* dsums = static_cast<uint8_t*>(c->d_sums);
+      for (const Item& it : items)
+        if (rc == OZCS_OK && e == hipSuccess)
+          e = hipMemcpyAsync(dd + it.data_off, chunks[it.idx].data, chunks[it.idx].len, hipMemcpyHostToDevice, c->stream);
+      for (int algo = 0; algo < 2 && rc == OZCS_OK && e == hipSuccess; algo++) {
+        const int type = algo == kAlgoSha256 ? OZCS_SHA256 : OZCS_MD5;
+        DigestJobList jl{};
+        jl.algo = algo;
+        auto launch = [&]() {
+          if (jl.n_jobs && e == hipSuccess) {
+            e = digest_launch_jobs(jl, c->stream);
+            s_launches.fetch_add(1, std::memory_order_relaxed);
+            s_windows.fetch_add(jl.n_windows, std::memory_order_relaxed);
+          }
+          jl.n_jobs = 0;
+          jl.n_windows = 0;
+        };
+        for (const Item& it : items) {
+          const ozcs_chunk& ch = chunks[it.idx];
+          if (ch.type != type) continue;
+          if (jl.n_jobs == (uint32_t)kMaxDigestJobs || (uint64_t)jl.n_windows + it.n > 0x7fffffffull) launch();
+          DigestJob& job = jl.jobs[jl.n_jobs++];
+          job.data = dd + it.data_off;
+          job.len = ch.len;
+          job.sums = dsums + it.sums_off;
+          job.bpc = ch.bpc;
+          job.first_window = jl.n_windows;
+          jl.n_windows += (uint32_t)it.n;
+          s_bytes.fetch_add(ch.len, std::memory_order_relaxed);
+        }
+        launch();
+      }
+      for (const Item& it : items) {
+        const ozcs_chunk& ch = chunks[it.idx];
+        if (ch.type != OZCS_CRC32 && ch.type != OZCS_CRC32C) continue;
+        if (rc == OZCS_OK && e == hipSuccess)
+          rc = launch_windows(*dev, ch.type, ch.bpc, dd + it.data_off, ch.len, 1, ch.len, kModeCompute,
+                              dsums + it.sums_off, nullptr, 0, 0, 0, nullptr, c->stream);
+      }
+      for (const Item& it : items)
+        if (rc == OZCS_OK && e == hipSuccess)
+          e = hipMemcpyAsync(chunks[it.idx].sums, dsums + it.sums_off, it.n * it.ds, hipMemcpyDeviceToHost, c->stream);
+      const hipError_t es = hipStreamSynchronize(c->stream);
+      if (rc == OZCS_OK && e != hipSuccess) rc = fail_hip(e, "batch enqueue");
+      if (rc == OZCS_OK && es != hipSuccess) rc = fail_hip(es, "hipStreamSynchronize");
+      for (const Item& it : items) {
+        chunks[it.idx].status = rc;
+        chunks[it.idx].n_sums = rc == OZCS_OK ? it.n : 0;
+        if (rc == OZCS_OK) {
+          s_h2d.fetch_add(chunks[it.idx].len, std::memory_order_relaxed);
+          s_d2h.fetch_add(it.n * it.ds, std::memory_order_relaxed);
+        }
+      }
+    }
+    i = group_end;
+  }
+  release_ctx(c);
+}
+
 }  // namespace ozcs
 
 using namespace ozcs;
@@ -434,31 +536,15 @@ int ozcs_compute_batch(ozcs_chunk* chunks, uint32_t n_chunks) {
   }
   Global& g = global();
   const size_t ndev = g.devs.size();
-  auto run_range = [&](size_t d, uint32_t lo, uint32_t hi) {
-    for (uint32_t i = lo; i < hi; i++) {
-      ozcs_chunk& ch = chunks[i];
-      ch.n_sums = 0;
-      int r = check_type_bpc(ch.type, ch.bpc);
-      if (r == OZCS_OK && ch.type != OZCS_NONE && ch.len != 0) {
-        const size_t ds = ozcs_digest_size(ch.type);
-        const uint64_t n = ozcs_num_checksums(ch.len, ch.bpc);
-        if (!ch.data || !ch.sums) r = fail(OZCS_EINVAL, "null pointer in chunk %u", i);
-        else if (ch.sums_cap < n * ds) r = fail(OZCS_EINVAL, "sums_cap too small in chunk %u", i);
-        else r = compute_host_on(g.devs[d].id, ch.type, ch.bpc, ch.data, ch.len, ch.sums, n, ds);
-        if (r == OZCS_OK) ch.n_sums = n;
-      }
-      ch.status = r;
-    }
-  };
   s_calls.fetch_add(1, std::memory_order_relaxed);
   if (ndev == 1 || n_chunks == 1) {
-    run_range(0, 0, n_chunks);
+    batch_on_device(g.devs[0].id, chunks, 0, n_chunks);
   } else {
     // contiguous shards of the chunk list, one host thread per device, no inter-device traffic
     std::vector<std::thread> th;
     for (size_t d = 0; d < ndev; d++) {
       const uint32_t lo = (uint32_t)((uint64_t)n_chunks * d / ndev), hi = (uint32_t)((uint64_t)n_chunks * (d + 1) / ndev);
-      if (lo < hi) th.emplace_back(run_range, d, lo, hi);
+      if (lo < hi) th.emplace_back(batch_on_device, g.devs[d].id, chunks, lo, hi);
     }
     for (auto& t : th) t.join();
   }

@@ -136,6 +136,37 @@ OZCS_API int ozcs_verify_device(int device, int type, uint32_t bpc, const void* 
                        uint64_t expected_stride, uint64_t n_expected, uint64_t start_index,
                        int64_t* d_first_mismatch, void* hip_stream);
 
+/* ---- asynchronous pinned pipeline: host buffer -> GPU -> digests back on the host ----
+ * The write path of BlockOutputStream (BlockOutputStream.java:495-507, 645-690) fills one chunk buffer while
+ * the previous one is checksummed and shipped.  A pipe gives that overlap across the PCIe link: n_slots
+ * pinned chunk buffers (taking the place of BufferPool's heap buffers, BufferPool.java:74-85), and three
+ * HIP streams chained by events: host-to-device copy of chunk n+1, kernel of chunk n and digest copy-back
+ * of chunk n-1 run concurrently.  Mixed checksum types per chunk are allowed.
+ * A pipe may be shared by threads (calls are serialised inside); tickets are slot numbers. */
+
+typedef struct ozcs_pipe ozcs_pipe;
+
+OZCS_API int ozcs_pipe_create(int device, uint32_t n_slots, uint64_t slot_bytes, ozcs_pipe** out);
+OZCS_API void ozcs_pipe_destroy(ozcs_pipe* pipe);
+
+/* Borrow a free slot: *buf is its pinned host buffer of slot_bytes bytes for the producer to fill in place
+ * (zero staging copies).  OZCS_EBUSY when every slot is in flight. */
+OZCS_API int ozcs_pipe_acquire(ozcs_pipe* pipe, void** buf, int* ticket);
+/* Queue copy + checksum + copy-back for the first `len` bytes of an acquired slot.  sums_out (host, any
+ * memory) receives the digests when the ticket completes. */
+OZCS_API int ozcs_pipe_submit_slot(ozcs_pipe* pipe, int ticket, int type, uint32_t bpc, uint64_t len,
+                                   void* sums_out, uint64_t sums_cap);
+/* Convenience for callers that already hold the chunk elsewhere (e.g. a heap byte[] pinned through
+ * GetPrimitiveArrayCritical): acquire + memcpy into the slot + submit. */
+OZCS_API int ozcs_pipe_submit(ozcs_pipe* pipe, int type, uint32_t bpc, const void* data, uint64_t len,
+                              void* sums_out, uint64_t sums_cap, int* ticket);
+/* OZCS_OK once the ticket's digests are in sums_out (the slot is free again), OZCS_EBUSY while in flight. */
+OZCS_API int ozcs_pipe_poll(ozcs_pipe* pipe, int ticket, uint64_t* n_sums);
+/* Blocks until the ticket completes. */
+OZCS_API int ozcs_pipe_wait(ozcs_pipe* pipe, int ticket, uint64_t* n_sums);
+/* Blocks until every submitted ticket has completed (their slots are freed). */
+OZCS_API int ozcs_pipe_drain(ozcs_pipe* pipe);
+
 /* ---- counters (no counterpart in the reference, which has no checksum-throughput metric) ---- */
 
 typedef struct ozcs_stats {

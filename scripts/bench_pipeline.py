@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""End-to-end host -> device -> host rate of the pinned pipeline (BASELINE config 5): 4 MiB chunks through
+ozcs_pipe slots, CRC32 : MD5 = 3 : 1 at 1 MiB windows, H2D copy / kernel / digest copy-back on three streams.
+Prints one JSON line per variant.  PCIe-bound by design: this is NOT the headline device-resident number."""
+import ctypes
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch  # noqa: F401  (shares its HIP runtime with the library)
+from hadoop_ozone_amd import native
+
+MIB = 1 << 20
+
+
+def run(L, n_slots, n_chunks, mix, staged):
+    pipe = ctypes.c_void_p()
+    native.check(L.ozcs_pipe_create(0, n_slots, 4 * MIB, ctypes.byref(pipe)))
+    src = np.random.default_rng(1).integers(0, 256, 4 * MIB, dtype=np.uint8)
+    outs = [ctypes.create_string_buffer(64) for _ in range(n_slots)]
+    buf, ticket, n = ctypes.c_void_p(), ctypes.c_int(), ctypes.c_uint64()
+    # fill every slot once
+    held = []
+    for _ in range(n_slots):
+        native.check(L.ozcs_pipe_acquire(pipe, ctypes.byref(buf), ctypes.byref(ticket)))
+        ctypes.memmove(buf.value, src.ctypes.data, 4 * MIB)
+        held.append(ticket.value)
+    for h in held:
+        native.check(L.ozcs_pipe_submit_slot(pipe, h, native.CRC32, MIB, 4 * MIB, outs[h], 64))
+    native.check(L.ozcs_pipe_drain(pipe))
+    order = []
+    t0 = time.perf_counter()
+    for i in range(n_chunks):
+        t = native.MD5 if (mix and i % 4 == 3) else native.CRC32
+        if staged:
+            while True:
+                rc = L.ozcs_pipe_submit(pipe, t, MIB, src.ctypes.data, 4 * MIB, outs[i % n_slots], 64, ctypes.byref(ticket))
+                if rc != native.EBUSY:
+                    break
+                native.check(L.ozcs_pipe_wait(pipe, order.pop(0), ctypes.byref(n)))
+            native.check(rc)
+        else:
+            while True:
+                rc = L.ozcs_pipe_acquire(pipe, ctypes.byref(buf), ctypes.byref(ticket))
+                if rc != native.EBUSY:
+                    break
+                native.check(L.ozcs_pipe_wait(pipe, order.pop(0), ctypes.byref(n)))
+            native.check(rc)
+            native.check(L.ozcs_pipe_submit_slot(pipe, ticket.value, t, MIB, 4 * MIB, outs[ticket.value], 64))
+        order.append(ticket.value)
+    native.check(L.ozcs_pipe_drain(pipe))
+    dt = time.perf_counter() - t0
+    L.ozcs_pipe_destroy(pipe)
+    return n_chunks * 4 * MIB / dt / 1e9
+
+
+def main():
+    L = native.lib()
+    native.check(L.ozcs_init(0))
+    for mix, staged, slots in ((False, False, 16), (False, True, 16), (True, False, 16), (True, False, 64),
+                               (True, False, 128), (True, False, 256), (True, True, 128)):
+        if True:
+            if True:
+                gbps = run(L, slots, 2048, mix, staged)
+                print(json.dumps({"metric": "end-to-end pinned pipeline GB/s", "value": round(gbps, 2), "unit": "GB/s",
+                                  "types": "CRC32:MD5 3:1" if mix else "CRC32", "slots": slots, "chunk_bytes": 4 * MIB,
+                                  "bytes_per_checksum": MIB,
+                                  "input": "memcpy from pageable memory into the slot" if staged else "produced in the pinned slot"}),
+                      flush=True)
+
+
+if __name__ == "__main__":
+    main()

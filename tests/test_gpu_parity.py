@@ -386,3 +386,75 @@ def test_reference_TestChecksum(gpu):
     assert got == [oracle.compute(oracle.CRC32, 20, r[:20]) for r in rag]
     with pytest.raises(OzoneChecksumException, match="Computed checksum has 5 number of checksums. Original checksum has 2"):
         Checksum.verifyChecksum(whole, ChecksumData(ChecksumType.CRC32, 20, cd.getChecksums()[:2]), 0)
+
+
+# ------------------------------------------------------------------ asynchronous pinned pipeline
+
+def test_pipe_mixed_types_against_oracle(gpu):
+    # BASELINE config 5 in miniature: host -> device -> host through pinned slots, CRC32 : MD5 = 3 : 1
+    torch, native, L = gpu
+    pipe = ctypes.c_void_p()
+    native.check(L.ozcs_pipe_create(0, 6, 4 * MIB, ctypes.byref(pipe)))
+    try:
+        jobs = []
+        pending = {}
+        rng = np.random.default_rng(17)
+
+        def reap(ticket):
+            j = pending.pop(ticket)
+            n = ctypes.c_uint64()
+            native.check(L.ozcs_pipe_wait(pipe, ticket, ctypes.byref(n)))
+            j["n"] = n.value
+
+        for i in range(40):
+            t = oracle.MD5 if i % 4 == 3 else oracle.CRC32
+            ln = 4 * MIB if i % 5 else int(rng.integers(1, 4 * MIB))
+            bpc = MIB if i % 7 else 16384
+            d = oracle.splitmix64(900 + i, ln)
+            ds = native.DIGEST_SIZE[t]
+            out = ctypes.create_string_buffer(((ln + bpc - 1) // bpc) * ds)
+            ticket = ctypes.c_int(-1)
+            if i % 2:   # producer fills the pinned slot in place
+                buf = ctypes.c_void_p()
+                while True:
+                    rc = L.ozcs_pipe_acquire(pipe, ctypes.byref(buf), ctypes.byref(ticket))
+                    if rc == native.EBUSY:
+                        reap(next(iter(pending)))
+                        continue
+                    native.check(rc)
+                    break
+                ctypes.memmove(buf.value, d.ctypes.data, ln)
+                native.check(L.ozcs_pipe_submit_slot(pipe, ticket.value, t, bpc, ln, out, len(out)))
+            else:       # data lives elsewhere: the library stages it
+                while True:
+                    rc = L.ozcs_pipe_submit(pipe, t, bpc, d.ctypes.data, ln, out, len(out), ctypes.byref(ticket))
+                    if rc == native.EBUSY:
+                        reap(next(iter(pending)))
+                        continue
+                    native.check(rc)
+                    break
+            j = {"t": t, "bpc": bpc, "d": d, "out": out}
+            jobs.append(j)
+            pending[ticket.value] = j
+        native.check(L.ozcs_pipe_drain(pipe))
+        for j in jobs:
+            exp = oracle.compute(j["t"], j["bpc"], j["d"])
+            assert j["out"].raw[: len(exp)] == exp
+        # all slots taken -> EBUSY; an unsubmitted ticket cannot be waited for; bad arguments are rejected
+        held = []
+        buf, ticket = ctypes.c_void_p(), ctypes.c_int()
+        for _ in range(6):
+            native.check(L.ozcs_pipe_acquire(pipe, ctypes.byref(buf), ctypes.byref(ticket)))
+            held.append(ticket.value)
+        assert L.ozcs_pipe_acquire(pipe, ctypes.byref(buf), ctypes.byref(ticket)) == native.EBUSY
+        assert L.ozcs_pipe_wait(pipe, held[0], None) == native.EINVAL
+        out = ctypes.create_string_buffer(64)
+        assert L.ozcs_pipe_submit_slot(pipe, held[0], 77, 1024, 4096, out, 64) == native.EINVAL   # slot is released
+        assert L.ozcs_pipe_submit_slot(pipe, held[1], oracle.CRC32, 1024, 8 * MIB, out, 64) == native.EINVAL
+        for h in held[2:]:
+            native.check(L.ozcs_pipe_submit_slot(pipe, h, oracle.NONE, 1024, 100, None, 0))
+            n = ctypes.c_uint64(9)
+            native.check(L.ozcs_pipe_wait(pipe, h, ctypes.byref(n)))
+            assert n.value == 0
+    finally:
+        L.ozcs_pipe_destroy(pipe)
