@@ -1,0 +1,207 @@
+// Host-side C++ mirror of the reference's checksum interface, over the C ABI (include/ozone_checksum.h).
+//
+// Same names, argument meaning and error behaviour as
+//   Checksum                 hadoop-hdds/common/src/main/java/org/apache/hadoop/ozone/common/Checksum.java:43-299
+//   ChecksumData             .../ozone/common/ChecksumData.java:34-192
+//   OzoneChecksumException   .../ozone/common/OzoneChecksumException.java:29-66
+//   ChecksumType             hadoop-hdds/interface-client/src/main/proto/DatanodeClientProtocol.proto:384-390
+// Every digest is computed by the GPU library; nothing here hashes on the CPU.  Header-only; link libozcs.so.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/ozone_checksum.h"
+
+namespace ozone {
+
+enum class ChecksumType : int { NONE = 1, CRC32 = 2, CRC32C = 3, SHA256 = 4, MD5 = 5 };
+
+inline const char* name(ChecksumType t) {
+  switch (t) {
+    case ChecksumType::NONE: return "NONE";
+    case ChecksumType::CRC32: return "CRC32";
+    case ChecksumType::CRC32C: return "CRC32C";
+    case ChecksumType::SHA256: return "SHA256";
+    case ChecksumType::MD5: return "MD5";
+  }
+  return "?";
+}
+
+using ByteString = std::string;  // immutable byte sequence, as com.google.protobuf.ByteString
+
+// An IOException in the reference (callers fail over to the next replica on it).
+class OzoneChecksumException : public std::runtime_error {
+ public:
+  explicit OzoneChecksumException(int index)  // OzoneChecksumException.java:35-37
+      : std::runtime_error("Checksum mismatch at index " + std::to_string(index)), index_(index) {}
+  explicit OzoneChecksumException(ChecksumType unrecognized)  // :43-47
+      : std::runtime_error(std::string("Unrecognized ChecksumType: ") + name(unrecognized)), index_(-1) {}
+  explicit OzoneChecksumException(const std::string& message) : std::runtime_error(message), index_(-1) {}  // :63-65
+  int index() const { return index_; }
+
+ private:
+  int index_;
+};
+
+// Raised when the GPU library itself cannot serve the call (no device, HIP failure): the caller keeps its
+// CPU path, as with NativeCRC32Wrapper.isAvailable() == false.
+class GpuUnavailable : public std::runtime_error {
+ public:
+  GpuUnavailable(int code, const std::string& msg) : std::runtime_error(msg), code(code) {}
+  int code;
+};
+
+class ChecksumData {
+ public:
+  ChecksumData(ChecksumType type, int bytesPerChecksum, std::vector<ByteString> checksums = {})
+      : type_(type), bytesPerChecksum_(bytesPerChecksum), checksums_(std::move(checksums)) {}
+
+  ChecksumType getChecksumType() const { return type_; }
+  int getBytesPerChecksum() const { return bytesPerChecksum_; }
+  const std::vector<ByteString>& getChecksums() const { return checksums_; }
+
+  // ChecksumData.java:117-149
+  bool verifyChecksumDataMatches(const ChecksumData& that, int startIndex) const {
+    if (checksums_.empty()) throw OzoneChecksumException("Original checksumData has no checksums");
+    if (that.checksums_.empty()) throw OzoneChecksumException("Computed checksumData has no checksums");
+    const size_t n = that.checksums_.size();
+    for (size_t index = 0; index < n; index++) {
+      const long long at = (long long)startIndex + (long long)index;
+      if (at < 0 || (size_t)at >= checksums_.size())
+        throw OzoneChecksumException("Computed checksum has " + std::to_string(n) +
+                                     " number of checksums. Original checksum has " +
+                                     std::to_string((long long)checksums_.size() - startIndex) +
+                                     " number of checksums starting from index " + std::to_string(startIndex));
+      if (checksums_[(size_t)at] != that.checksums_[index]) throw OzoneChecksumException((int)index);
+    }
+    return true;
+  }
+
+  bool operator==(const ChecksumData& o) const {  // :156-182
+    return type_ == o.type_ && bytesPerChecksum_ == o.bytesPerChecksum_ && checksums_ == o.checksums_;
+  }
+  bool operator!=(const ChecksumData& o) const { return !(*this == o); }
+
+  // Serialised ContainerProtos.ChecksumData (DatanodeClientProtocol.proto:378-382), ChecksumData.java:78-87.
+  ByteString getProtoBufMessage() const {
+    ByteString out;
+    out.push_back(0x08); putVarint(out, (uint64_t)(int)type_);
+    out.push_back(0x10); putVarint(out, (uint64_t)(uint32_t)bytesPerChecksum_);
+    for (const ByteString& c : checksums_) { out.push_back(0x1a); putVarint(out, c.size()); out += c; }
+    return out;
+  }
+
+ private:
+  static void putVarint(ByteString& o, uint64_t v) {
+    while (v >= 0x80) { o.push_back((char)(v | 0x80)); v >>= 7; }
+    o.push_back((char)v);
+  }
+  ChecksumType type_;
+  int bytesPerChecksum_;
+  std::vector<ByteString> checksums_;
+};
+
+// Checksum.java:43-299.
+class Checksum {
+ public:
+  Checksum(ChecksumType type, int bytesPerChecksum) : checksumType_(type), bytesPerChecksum_(bytesPerChecksum) {}
+
+  static ByteString int2ByteString(int32_t n) {  // Checksum.java:62-64
+    const uint32_t u = (uint32_t)n;
+    return ByteString{(char)(u >> 24), (char)(u >> 16), (char)(u >> 8), (char)u};
+  }
+
+  // computeChecksum(byte[] / byte[],off,len / ByteBuffer): Checksum.java:119-146
+  ChecksumData computeChecksum(const void* data, size_t len) const {
+    if (checksumType_ == ChecksumType::NONE) return ChecksumData(checksumType_, bytesPerChecksum_);  // :157-160
+    const int t = (int)checksumType_;
+    if (t < OZCS_NONE || t > OZCS_MD5) throw OzoneChecksumException(checksumType_);  // :163-167
+    if (bytesPerChecksum_ <= 0) throw std::invalid_argument("bytesPerChecksum must be positive");
+    const size_t ds = ozcs_digest_size(t);
+    const uint64_t n = ozcs_num_checksums(len, (uint32_t)bytesPerChecksum_);
+    std::string raw(n * ds, '\0');
+    uint64_t got = 0;
+    check(ozcs_compute(t, (uint32_t)bytesPerChecksum_, data, len, raw.empty() ? nullptr : &raw[0], raw.size(), &got));
+    return ChecksumData(checksumType_, bytesPerChecksum_, split(raw, ds, got));
+  }
+
+  // computeChecksum(List<ByteString>) / computeChecksum(ChunkBuffer over a list): one element per window; an
+  // element longer than bytesPerChecksum contributes only its first bytesPerChecksum bytes
+  // (Checksum.java:148-153, 186-198).  Every element is checksummed.
+  ChecksumData computeChecksum(const std::vector<ByteString>& byteStrings) const {
+    if (checksumType_ == ChecksumType::NONE) return ChecksumData(checksumType_, bytesPerChecksum_);
+    const int t = (int)checksumType_;
+    if (t < OZCS_NONE || t > OZCS_MD5) throw OzoneChecksumException(checksumType_);
+    if (bytesPerChecksum_ <= 0) throw std::invalid_argument("bytesPerChecksum must be positive");
+    const size_t ds = ozcs_digest_size(t);
+    std::vector<ozcs_chunk> jobs;
+    std::vector<ByteString> outs;
+    for (const ByteString& b : byteStrings)
+      if (!b.empty()) outs.emplace_back(ds, '\0');
+    size_t k = 0;
+    for (const ByteString& b : byteStrings) {
+      if (b.empty()) continue;
+      ozcs_chunk c{};
+      c.data = b.data();
+      c.len = b.size() < (size_t)bytesPerChecksum_ ? b.size() : (size_t)bytesPerChecksum_;
+      c.sums = &outs[k][0];
+      c.sums_cap = ds;
+      c.bpc = (uint32_t)bytesPerChecksum_;
+      c.type = t;
+      jobs.push_back(c);
+      k++;
+    }
+    if (!jobs.empty()) check(ozcs_compute_batch(jobs.data(), (uint32_t)jobs.size()));
+    return ChecksumData(checksumType_, bytesPerChecksum_, outs);
+  }
+
+  // verifyChecksum(ByteString, ChecksumData, int) / (byte[], ChecksumData): Checksum.java:210-250.
+  static bool verifyChecksum(const void* data, size_t len, const ChecksumData& checksumData, int startIndex = 0) {
+    const ChecksumType type = checksumData.getChecksumType();
+    if (type == ChecksumType::NONE) return true;  // :241-244
+    const int t = (int)type;
+    if (t < OZCS_NONE || t > OZCS_MD5) throw OzoneChecksumException(type);
+    std::string stored;
+    for (const ByteString& c : checksumData.getChecksums()) stored += c;
+    const size_t ds = ozcs_digest_size(t);
+    int64_t first = -1;
+    if (startIndex < 0) throw std::out_of_range("startIndex");
+    const int rc = ozcs_verify(t, (uint32_t)checksumData.getBytesPerChecksum(), data, len, stored.data(),
+                               ds ? stored.size() / ds : 0, (uint64_t)startIndex, &first);
+    if (rc == OZCS_EEMPTY || rc == OZCS_ERANGE) throw OzoneChecksumException(std::string(ozcs_last_error()));
+    check(rc);
+    if (first >= 0) throw OzoneChecksumException((int)first);
+    return true;
+  }
+
+  // verifyChecksum(List<ByteString>, ChecksumData, int, boolean): Checksum.java:265-290.
+  static bool verifyChecksum(const std::vector<ByteString>& byteStrings, const ChecksumData& checksumData,
+                             int startIndex, bool isSingleByteString) {
+    if (checksumData.getChecksumType() == ChecksumType::NONE) return true;  // :269-272
+    if (isSingleByteString)
+      return verifyChecksum(byteStrings.at(0).data(), byteStrings.at(0).size(), checksumData, startIndex);  // :274-277
+    const ChecksumData computed =
+        Checksum(checksumData.getChecksumType(), checksumData.getBytesPerChecksum()).computeChecksum(byteStrings);
+    return checksumData.verifyChecksumDataMatches(computed, startIndex);  // :282-289
+  }
+
+ private:
+  static void check(int rc) {
+    if (rc == OZCS_OK) return;
+    throw GpuUnavailable(rc, std::string("ozcs error ") + std::to_string(rc) + ": " + ozcs_last_error());
+  }
+  static std::vector<ByteString> split(const std::string& raw, size_t ds, uint64_t n) {
+    std::vector<ByteString> v;
+    v.reserve(n);
+    for (uint64_t i = 0; i < n; i++) v.emplace_back(raw.substr(i * ds, ds));
+    return v;
+  }
+  ChecksumType checksumType_;
+  int bytesPerChecksum_;
+};
+
+}  // namespace ozone

@@ -1,0 +1,72 @@
+/*
+ * Java side of the JNI binding for libozcs (include/ozone_checksum.h).  Source only: the build image has no
+ * JDK.  Modelled on org.apache.hadoop.util.NativeCRC32Wrapper (static methods, caller-allocated sums,
+ * isAvailable() probe) so that Checksum can use it the way the reference's benchmarks use the Hadoop
+ * native CRC.  Type constants are ContainerProtos.ChecksumType numbers, not Hadoop's 1/2.
+ */
+package org.apache.hadoop.ozone.common;
+
+import java.nio.ByteBuffer;
+
+public final class GpuChecksum {
+  private static final boolean AVAILABLE;
+
+  static {
+    boolean ok = false;
+    try {
+      System.loadLibrary("ozcs_jni");   // links libozcs.so
+      ok = nativeAvailable();
+    } catch (UnsatisfiedLinkError e) {
+      ok = false;                         // no library on java.library.path: keep the Java engines
+    }
+    AVAILABLE = ok;
+  }
+
+  private GpuChecksum() { }
+
+  /** True when a gfx950 device is usable; callers keep the pure-Java path otherwise. */
+  public static boolean isAvailable() {
+    return AVAILABLE;
+  }
+
+  /** ozcs_digest_size. */
+  public static int digestSize(int checksumType) {
+    switch (checksumType) {
+    case 2: case 3: return 4;
+    case 4: return 32;
+    case 5: return 16;
+    default: return 0;
+    }
+  }
+
+  /**
+   * ozcs_compute over a heap array: ceil(dataLength / bytesPerSum) digests are written to
+   * sums[sumsOffset ...].  Returns the digest count, or a negative OZCS_E* code (ENODEV / EHIP: fall back).
+   * Shape of NativeCRC32Wrapper.calculateChunkedSumsByteArray.
+   */
+  public static native long calculateChunkedSumsByteArray(int bytesPerSum, int checksumType,
+      byte[] sums, int sumsOffset, byte[] data, int dataOffset, int dataLength);
+
+  /** Same for direct buffers (position..limit of data; digests at sums.position()). */
+  public static native long calculateChunkedSums(int bytesPerSum, int checksumType,
+      ByteBuffer sums, ByteBuffer data);
+
+  /**
+   * ozcs_verify: returns -1 when every window matches, the first mismatching index (relative to the
+   * computed list) otherwise, or a code below -1 ( -1 + OZCS_E* ) when the library could not run.
+   * Shape of NativeCRC32Wrapper.verifyChunkedSumsByteArray.
+   */
+  public static native long verifyChunkedSumsByteArray(int bytesPerSum, int checksumType,
+      byte[] sums, int sumsOffset, int numSums, int startIndex, byte[] data, int dataOffset, int dataLength);
+
+  // ---- pinned pipeline: replaces BufferPool's heap buffers by pinned direct buffers ----
+  public static native long pipeCreate(int device, int slots, long slotBytes);
+  public static native void pipeDestroy(long pipe);
+  /** Returns a direct ByteBuffer over a free pinned slot (its ticket is returned in ticketOut[0]), or null. */
+  public static native ByteBuffer pipeAcquire(long pipe, int[] ticketOut);
+  public static native int pipeSubmit(long pipe, int ticket, int checksumType, int bytesPerSum, long length,
+      ByteBuffer sums);
+  public static native long pipeWait(long pipe, int ticket);
+
+  private static native boolean nativeAvailable();
+}

@@ -458,3 +458,16 @@ def test_pipe_mixed_types_against_oracle(gpu):
             assert n.value == 0
     finally:
         L.ozcs_pipe_destroy(pipe)
+
+
+# ------------------------------------------------------------------ C++ host mirror, in a process without PyTorch
+
+def test_cpp_host_mirror_standalone(gpu):
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tests", "cpp", "host_mirror_test")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all passed" in r.stdout
