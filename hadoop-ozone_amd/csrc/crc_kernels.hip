@@ -145,6 +145,71 @@ __device__ __forceinline__ uint4 init_spill(uintptr_t u, uintptr_t s) {
 }
 __device__ __forceinline__ uint4 xor4(uint4 a, uint4 b) { return make_uint4(a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w); }
 
+// Builds the LDS tables from the 32-entry operator bases: the four byte tables of operator `main_op` in
+// 32 copies, and the nibble tables of operators 0..kNibOps-1.  All kThreads threads take part.
+__device__ __forceinline__ void build_tables(char* lds, const PolyBasis& pb, int main_op, int tid) {
+  const int j = tid >> 8, b = tid & 255;  // byte table j, entry b
+  uint32_t v = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) v ^= ((b >> i) & 1) ? pb.op[main_op].v[8 * j + i] : 0u;
+  uint4* dst = reinterpret_cast<uint4*>(lds + (j >> 1) * 65536 + b * 256 + (j & 1) * 128);
+  const uint4 v4 = make_uint4(v, v, v, v);
+#pragma unroll
+  for (int r = 0; r < 8; r++) dst[r] = v4;
+  for (int e = tid; e < kNibOps * 128; e += kThreads) {
+    const int op = e >> 7, q = (e >> 4) & 7, nv = e & 15;
+    uint32_t w = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) w ^= ((nv >> i) & 1) ? pb.op[op].v[4 * q + i] : 0u;
+    *reinterpret_cast<uint32_t*>(lds + kNibOff + e * 4) = w;
+  }
+}
+
+// Stores (compute) or checks (verify) the digest `be` (already big-endian in memory order) of window g.
+template <int MODE>
+__device__ __forceinline__ void emit(const CrcLaunch& p, uint64_t g, uint64_t chunk, uint64_t wi, uint32_t be) {
+  if (MODE == kModeCompute) {
+    uint8_t* out = p.sums + g * 4;
+    if ((reinterpret_cast<uintptr_t>(out) & 3) == 0) {
+      *reinterpret_cast<uint32_t*>(out) = be;
+    } else {
+      out[0] = (uint8_t)be; out[1] = (uint8_t)(be >> 8); out[2] = (uint8_t)(be >> 16); out[3] = (uint8_t)(be >> 24);
+    }
+  } else {
+    // ChecksumData.verifyChecksumDataMatches: stored[startIndex + i] against computed[i]
+    const uint64_t si = p.start_index + wi;
+    bool bad;
+    if (si >= p.n_expected) {
+      bad = true;
+    } else {
+      const uint8_t* ex = p.expected + chunk * p.expected_stride + si * 4;
+      uint32_t ev;
+      if ((reinterpret_cast<uintptr_t>(ex) & 3) == 0) ev = *reinterpret_cast<const uint32_t*>(ex);
+      else ev = (uint32_t)ex[0] | ((uint32_t)ex[1] << 8) | ((uint32_t)ex[2] << 16) | ((uint32_t)ex[3] << 24);
+      bad = ev != be;
+    }
+    if (bad) atomicMin(p.first_mismatch + chunk, (unsigned long long)wi);
+  }
+}
+
+// Finishes a window: the bytes behind its last 16-byte boundary (or all of a tiny window) bit-serially,
+// then getValue() and Ints.toByteArray.
+__device__ __forceinline__ uint32_t finish_window(uint32_t state, bool vec, uintptr_t s, uintptr_t e16, uintptr_t e, uint32_t poly) {
+  uintptr_t tb = e16;
+  if (!vec) {
+    state = 0xFFFFFFFFu;
+    tb = s;
+  }
+  for (; tb < e; tb++)
+    state = crc_byte_bitwise(state, *reinterpret_cast<const __attribute__((address_space(1))) uint8_t*>(tb), poly);
+  return __builtin_bswap32(~state);
+}
+
+__device__ __forceinline__ uint32_t slot_fold(const char* nib, const Acc4& a) {
+  return nib_apply(nib + kOpZ16 * kNibOpBytes, a.a0) ^ nib_apply(nib + kOpZ12 * kNibOpBytes, a.a1) ^
+         nib_apply(nib + kOpZ8 * kNibOpBytes, a.a2) ^ nib_apply(nib + kOpZ4 * kNibOpBytes, a.a3);
+}
+
 // Folds the accumulators of a wavefront's two rows.  The result, valid in lane 63, is the register a
 // zero-initialised CRC would hold after the 2 KiB the 512 accumulators spell out.  Row A lies 1 KiB in
 // front of row B, so lane by lane A is advanced by 1 KiB and merged into B before the lanes are folded.
@@ -175,24 +240,7 @@ __global__ __launch_bounds__(kThreads) void crc_windows_kernel(const CrcLaunch p
   const int wave = tid >> 6;
   const PolyBasis& pb = c_basis[p.poly_idx];
 
-  // ---- build the LDS tables from the 32-entry operator bases ----
-  {
-    const int j = tid >> 8, b = tid & 255;  // byte table j, entry b
-    uint32_t v = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) v ^= ((b >> i) & 1) ? pb.op[kMainOp].v[8 * j + i] : 0u;
-    uint4* dst = reinterpret_cast<uint4*>(lds + (j >> 1) * 65536 + b * 256 + (j & 1) * 128);
-    const uint4 v4 = make_uint4(v, v, v, v);
-#pragma unroll
-    for (int r = 0; r < 8; r++) dst[r] = v4;
-    for (int e = tid; e < kNibOps * 128; e += kThreads) {
-      const int op = e >> 7, q = (e >> 4) & 7, nv = e & 15;
-      uint32_t w = 0;
-#pragma unroll
-      for (int i = 0; i < 4; i++) w ^= ((nv >> i) & 1) ? pb.op[op].v[4 * q + i] : 0u;
-      *reinterpret_cast<uint32_t*>(lds + kNibOff + e * 4) = w;
-    }
-  }
+  build_tables(lds, pb, kMainOp, tid);
   __syncthreads();
 
   const char* nib = lds + kNibOff;
@@ -295,42 +343,112 @@ __global__ __launch_bounds__(kThreads) void crc_windows_kernel(const CrcLaunch p
     }
     if (!valid) continue;
 
-    // ---- bytes behind the last 16-byte boundary (or the whole of a tiny window), bit-serial ----
-    uintptr_t tb = e16;
-    if (!vec) {
-      state = 0xFFFFFFFFu;
-      tb = s;
-    }
-    const uint32_t poly = p.poly_idx ? kPolyCrc32c : kPolyCrc32;
-    for (; tb < e; tb++)
-      state = crc_byte_bitwise(state, *reinterpret_cast<const __attribute__((address_space(1))) uint8_t*>(tb), poly);
-    const uint32_t be = __builtin_bswap32(~state);  // getValue() then Ints.toByteArray
+    const uint32_t be = finish_window(state, vec, s, e16, e, p.poly_idx ? kPolyCrc32c : kPolyCrc32);
+    if (lane == 0) emit<MODE>(p, g, chunk, wi, be);
+  }
+}
 
-    if (lane == 0) {
-      if (MODE == kModeCompute) {
-        uint8_t* out = p.sums + g * 4;
-        if ((reinterpret_cast<uintptr_t>(out) & 3) == 0) {
-          *reinterpret_cast<uint32_t*>(out) = be;
-        } else {
-          out[0] = (uint8_t)be; out[1] = (uint8_t)(be >> 8); out[2] = (uint8_t)(be >> 16); out[3] = (uint8_t)(be >> 24);
-        }
-      } else {
-        // ChecksumData.verifyChecksumDataMatches: stored[startIndex + i] against computed[i]
-        const uint64_t si = p.start_index + wi;
-        bool bad;
-        if (si >= p.n_expected) {
-          bad = true;
-        } else {
-          const uint8_t* ex = p.expected + chunk * p.expected_stride + si * 4;
-          uint32_t ev;
-          if ((reinterpret_cast<uintptr_t>(ex) & 3) == 0) ev = *reinterpret_cast<const uint32_t*>(ex);
-          else ev = (uint32_t)ex[0] | ((uint32_t)ex[1] << 8) | ((uint32_t)ex[2] << 16) | ((uint32_t)ex[3] << 24);
-          bad = ev != be;
-        }
-        if (bad) atomicMin(p.first_mismatch + chunk, (unsigned long long)wi);
-      }
+// Small windows: LPW lanes per window, so one wavefront row holds 64/LPW windows and a wavefront works on
+// 2*64/LPW windows at once.  Same inner loop (stripe = 16*LPW bytes of each window), but the fold is shared:
+// log2(LPW) tree levels serve all windows of a row.  Window geometry is per lane; lanes whose window has
+// fewer stripes simply stop absorbing earlier.
+struct Win {
+  uintptr_t s, e, e16;
+  uint64_t chunk, wi;
+  uint32_t nst;  // stripes of the aligned part (0: nothing to vectorise)
+  bool valid, vec;
+};
+
+template <uint32_t kStripe>
+__device__ __forceinline__ Win window_of(const CrcLaunch& p, uint64_t g) {
+  Win w{};
+  w.valid = g < p.n_windows;
+  if (w.valid) {
+    w.chunk = g / p.wpc;
+    w.wi = g - w.chunk * p.wpc;
+    const uint64_t woff = w.wi * (uint64_t)p.bpc;
+    const uint64_t left = p.chunk_len - woff;
+    const uint64_t len = left < p.bpc ? left : p.bpc;
+    w.s = reinterpret_cast<uintptr_t>(p.data) + w.chunk * p.chunk_stride + woff;
+    w.e = w.s + len;
+    w.e16 = w.e & ~(uintptr_t)15;
+    w.vec = w.e16 >= w.s + 4;
+    if (w.vec) w.nst = (uint32_t)((w.e16 - (w.s & ~(uintptr_t)15) + kStripe - 1) / kStripe);
+  }
+  return w;
+}
+
+template <int LPW, int MODE>
+__global__ __launch_bounds__(kThreads) void crc_subwave_kernel(const CrcLaunch p) {
+  __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
+  constexpr uint32_t kStripe = 16u * LPW;
+  constexpr int kWinPerRow = 64 / LPW;
+  constexpr int kWinPerWave = 2 * kWinPerRow;
+  constexpr int kLevels = LPW == 4 ? 2 : LPW == 8 ? 3 : LPW == 16 ? 4 : 5;
+  constexpr int kMainOp = kOpZ16 + kLevels;  // advance by 16*LPW bytes
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  build_tables(lds, c_basis[p.poly_idx], kMainOp, tid);
+  __syncthreads();
+
+  const char* nib = lds + kNibOff;
+  const uint32_t lb01 = (uint32_t)(lane & 31) * 4u;
+  const uint32_t lb23 = lb01 + 65536u;
+  const int sl = lane & (LPW - 1);  // lane inside its window's group
+  const int grp = lane / LPW;
+  const uint32_t poly = p.poly_idx ? kPolyCrc32c : kPolyCrc32;
+
+  for (uint64_t w0 = ((uint64_t)blockIdx.x * kWaves + wave) * kWinPerWave; w0 < p.n_windows;
+       w0 += (uint64_t)gridDim.x * kWaves * kWinPerWave) {
+    const uint64_t ga = w0 + grp, gb = w0 + kWinPerRow + grp;
+    const Win wa = window_of<kStripe>(p, ga), wb = window_of<kStripe>(p, gb);
+    uintptr_t ua = wa.e16 - (uintptr_t)wa.nst * kStripe + 16u * sl;
+    uintptr_t ub = wb.e16 - (uintptr_t)wb.nst * kStripe + 16u * sl;
+    Acc4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+    if (wa.nst) a = first_unit(ua, wa.s);
+    if (wb.nst) b = first_unit(ub, wb.s);
+    ua += kStripe;
+    ub += kStripe;
+    uint4 na = make_uint4(0, 0, 0, 0), nb = make_uint4(0, 0, 0, 0);
+    if (1 < wa.nst) na = xor4(ld16(ua), init_spill(ua, wa.s));
+    if (1 < wb.nst) nb = xor4(ld16(ub), init_spill(ub, wb.s));
+    for (uint32_t j = 1; __ballot(j < wa.nst || j < wb.nst) != 0ull; j++) {
+      const uint4 ca = na, cb = nb;
+      ua += kStripe;
+      ub += kStripe;
+      if (j + 1 < wa.nst) na = ld16(ua);
+      if (j + 1 < wb.nst) nb = ld16(ub);
+      if (j < wa.nst) absorb(lds, lb01, lb23, a, ca);
+      if (j < wb.nst) absorb(lds, lb01, lb23, b, cb);
+    }
+    uint32_t x = slot_fold(nib, a), y = slot_fold(nib, b);
+#pragma unroll
+    for (int i = 0; i < kLevels; i++) {
+      uint32_t tx = __shfl_up(x, 1u << i, 64), ty = __shfl_up(y, 1u << i, 64);
+      tx = nib_apply(nib + (kOpZ16 + i) * kNibOpBytes, tx);
+      ty = nib_apply(nib + (kOpZ16 + i) * kNibOpBytes, ty);
+      x ^= (sl >= (1 << i)) ? tx : 0u;
+      y ^= (sl >= (1 << i)) ? ty : 0u;
+    }
+    if (sl == LPW - 1) {  // the last lane of a group holds its window's register
+      if (wa.valid) emit<MODE>(p, ga, wa.chunk, wa.wi, finish_window(x, wa.vec, wa.s, wa.e16, wa.e, poly));
+      if (wb.valid) emit<MODE>(p, gb, wb.chunk, wb.wi, finish_window(y, wb.vec, wb.s, wb.e16, wb.e, poly));
     }
   }
+}
+
+template <int MODE>
+hipError_t launch_subwave(const CrcLaunch& p, int lpw, int blocks, hipStream_t stream) {
+  switch (lpw) {
+    case 4: crc_subwave_kernel<4, MODE><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 8: crc_subwave_kernel<8, MODE><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 16: crc_subwave_kernel<16, MODE><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 32: crc_subwave_kernel<32, MODE><<<blocks, kThreads, 0, stream>>>(p); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
 }
 
 template <int MODE, int PF>
@@ -353,6 +471,7 @@ int env_int(const char* name) {
 }
 const int g_force_group = env_int("OZCS_CRC_GROUP");
 const int g_force_pf = env_int("OZCS_CRC_PF");
+const int g_force_lpw = env_int("OZCS_CRC_LPW");  // 4|8|16|32 lanes per window, 64 = never use the small-window kernel
 
 }  // namespace
 
@@ -368,8 +487,31 @@ int crc_choose_group(uint64_t n_windows, uint32_t bpc, int num_cus) {
   return g;
 }
 
+// Lanes per window for the small-window kernel, or 0 to use the wavefront-per-window kernels.  Measured on
+// MI355X (8 GiB batches): 8 lanes per window is fastest from 512 B to 64 KiB windows (6.3 TB/s at 16 KiB
+// against 5.3 for a wavefront per window; 3.7 against 0.55 at 512 B); 4 lanes read 64-byte pieces and stop
+// at 3.6 TB/s.  Fewer windows ask for more lanes each so that every wavefront still has work; tiny windows
+// cap the lanes so that a window still spans a few stripes.
+int crc_choose_lpw(uint64_t n_windows, uint32_t bpc, int num_cus) {
+  if (g_force_lpw == 4 || g_force_lpw == 8 || g_force_lpw == 16 || g_force_lpw == 32) return g_force_lpw;
+  if (g_force_lpw == 64) return 0;
+  if (bpc > 65536) return 0;
+  const uint64_t waves = (uint64_t)num_cus * kWaves;
+  const int want = n_windows >= waves * 16 ? 8 : n_windows >= waves * 8 ? 16 : n_windows >= waves * 4 ? 32 : 64;
+  const int cap = bpc >= 4096 ? 64 : bpc >= 2048 ? 32 : bpc >= 1024 ? 16 : bpc >= 512 ? 8 : 4;
+  const int lpw = want < cap ? want : cap;
+  return lpw == 64 ? 0 : lpw;
+}
+
 hipError_t crc_launch(const CrcLaunch& p, int mode, int group, int num_cus, hipStream_t stream) {
   if (p.n_windows == 0) return hipSuccess;
+  if (const int lpw = crc_choose_lpw(p.n_windows, p.bpc, num_cus)) {
+    const uint64_t per_block = (uint64_t)kWaves * 2 * (64 / lpw);
+    uint64_t nb = (p.n_windows + per_block - 1) / per_block;
+    if (nb > (uint64_t)num_cus) nb = num_cus;
+    return mode == kModeCompute ? launch_subwave<kModeCompute>(p, lpw, (int)nb, stream)
+                                : launch_subwave<kModeVerify>(p, lpw, (int)nb, stream);
+  }
   const uint64_t per_block = kWaves / group;
   uint64_t blocks = (p.n_windows + per_block - 1) / per_block;
   if (blocks > (uint64_t)num_cus) blocks = num_cus;  // 138 KiB of LDS: one block per CU, persistent

@@ -95,6 +95,15 @@ CRC_SHAPES = [
     (3, 100000, 100000, 512),                      # HDFS-style 512-byte windows
     (2, 1000, 1000, 10),                           # TestChecksum-sized windows
     (1, 777, 777, 1),                              # one byte per checksum
+    # >= 8192 windows: the small-window kernel (4, 8, 16, 32 lanes per window)
+    (9, 512 * 1024 + 77, 512 * 1024 + 80, 512),
+    (20, 450000, 450001, 1024),
+    (33, 1000003, 1000003, 4096),
+    (40, 4 * MIB, 4 * MIB, 16384),
+    (3, 100000, 100000, 10),
+    (7, 1500000, 1500007, 1000),
+    (5, 9000001, 9000001, 4099),
+    (2, 70 * MIB + 5, 70 * MIB + 16, 16400),
 ]
 
 
@@ -203,7 +212,7 @@ def test_verify_device_first_mismatch_per_chunk(gpu, t, bpc):
 def test_verify_k_corrupted_windows_at_speed(gpu):
     # config 3 shape scaled to one GPU-second of oracle work: CRC32C, 16 KiB windows, k in {0, 1, 1000}
     torch, native, L = gpu
-    bpc, chunk_len, n_chunks = 16384, 4 * MIB, 64
+    bpc, chunk_len, n_chunks = 16384, 4 * MIB, 256   # 65,536 windows: eight lanes per window
     wpc = chunk_len // bpc
     g = torch.Generator(device="cuda")
     g.manual_seed(3)
