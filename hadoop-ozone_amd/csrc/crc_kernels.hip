@@ -53,20 +53,26 @@ __device__ __forceinline__ uint32_t lds_u32(const char* base, uint32_t off) {
   return *reinterpret_cast<const uint32_t*>(base + off);
 }
 
+// a ^ b ^ c in one instruction (v_bitop3_b32, truth table 0x96).
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+  return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+}
+
 // x * x^(8*n) mod P through the 16-entry nibble tables of one operator.
 __device__ __forceinline__ uint32_t nib_apply(const char* op_tab, uint32_t x) {
-  uint32_t r = 0;
+  uint32_t t[8];
 #pragma unroll
   for (int q = 0; q < 8; q++) {
     const uint32_t idx4 = (q == 0) ? ((x << 2) & 0x3cu) : ((x >> (4 * q - 2)) & 0x3cu);
-    r ^= lds_u32(op_tab, q * 64 + idx4);
+    t[q] = lds_u32(op_tab, q * 64 + idx4);
   }
-  return r;
+  return xor3(xor3(t[0], t[1], t[2]), xor3(t[3], t[4], t[5]), t[6] ^ t[7]);
 }
 
 struct Acc4 {
   uint32_t a0, a1, a2, a3;
 };
+
 
 // LDS addresses of the four table entries an accumulator selects.  Tables 0/1 share rows of 256 B
 // (entry b of table t, copy r at b*256 + t*128 + r*4) and so do tables 2/3, 64 KiB further on; with
@@ -88,7 +94,7 @@ __device__ __forceinline__ uint32_t gather4(const char* lds, const Rows4& r, uin
   const uint32_t t1 = lds_u32(lds, r.o1 + 128u);
   const uint32_t t2 = lds_u32(lds, r.o2);
   const uint32_t t3 = lds_u32(lds, r.o3 + 128u);
-  return (t0 ^ t1) ^ (t2 ^ t3) ^ d;
+  return xor3(xor3(t0, t1, t2), t3, d);
 }
 
 // One stripe step for the four accumulators of a 16-byte unit: acc = acc * x^(8*stripe) ^ dword.

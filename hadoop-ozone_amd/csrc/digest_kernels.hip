@@ -28,6 +28,8 @@ typedef const __attribute__((address_space(1))) uint8_t* gptr_u8;
 
 __device__ __forceinline__ uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
 __device__ __forceinline__ uint32_t rotl(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
+// Three-input bitwise functions in one instruction (v_bitop3_b32; the table is the function of 0xF0, 0xCC, 0xAA).
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
 
 // ------------------------------------------------------------------ SHA-256 (FIPS 180-4, 6.2.2)
 __constant__ const uint32_t kK256[64] = {
@@ -56,14 +58,14 @@ struct Sha256 {
         wi = w[i];
       } else {
         const uint32_t w15 = w[(i + 1) & 15], w2 = w[(i + 14) & 15];
-        const uint32_t s0 = rotr(w15, 7) ^ rotr(w15, 18) ^ (w15 >> 3);
-        const uint32_t s1 = rotr(w2, 17) ^ rotr(w2, 19) ^ (w2 >> 10);
+        const uint32_t s0 = xor3(rotr(w15, 7), rotr(w15, 18), w15 >> 3);
+        const uint32_t s1 = xor3(rotr(w2, 17), rotr(w2, 19), w2 >> 10);
         wi = w[i & 15] = w[i & 15] + s0 + w[(i + 9) & 15] + s1;
       }
-      const uint32_t S1 = rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25);
+      const uint32_t S1 = xor3(rotr(e, 6), rotr(e, 11), rotr(e, 25));
       const uint32_t ch = (e & f) ^ (~e & g);
       const uint32_t t1 = hh + S1 + ch + kK256[i] + wi;
-      const uint32_t S0 = rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22);
+      const uint32_t S0 = xor3(rotr(a, 2), rotr(a, 13), rotr(a, 22));
       const uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
       const uint32_t t2 = S0 + mj;
       hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
@@ -98,7 +100,7 @@ struct Md5 {
       int g;
       if (i < 16) { f = (b & c) | (~b & d); g = i; }
       else if (i < 32) { f = (d & b) | (~d & c); g = (5 * i + 1) & 15; }
-      else if (i < 48) { f = b ^ c ^ d; g = (3 * i + 5) & 15; }
+      else if (i < 48) { f = xor3(b, c, d); g = (3 * i + 5) & 15; }
       else { f = c ^ (b | ~d); g = (7 * i) & 15; }
       const uint32_t t = d;
       d = c;
