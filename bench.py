@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--blocks", type=int, default=32, help="256 MiB blocks resident per GPU (32 = 8 GiB)")
+    ap.add_argument("--blocks", type=int, default=64, help="256 MiB blocks resident per GPU (64 = 16 GiB)")
     ap.add_argument("--type", default="CRC32", choices=["CRC32", "CRC32C", "SHA256", "MD5"])
     ap.add_argument("--bpc", type=int, default=MIB)
     ap.add_argument("--mode", default="compute", choices=["compute", "verify"])

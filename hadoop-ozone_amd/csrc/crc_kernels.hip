@@ -484,11 +484,13 @@ const int g_force_lpw = env_int("OZCS_CRC_LPW");  // 4|8|16|32 lanes per window,
 int crc_choose_group(uint64_t n_windows, uint32_t bpc, int num_cus) {
   if (g_force_group == 1 || g_force_group == 2 || g_force_group == 4 || g_force_group == 8 || g_force_group == 16)
     return g_force_group;
-  // Use as few wavefronts per window as still fills the chip (a fold per wavefront per window is
-  // the fixed cost), but never give a wavefront less than ~8 KiB when it can be avoided.
+  // Measured on MI355X at 1 MiB windows (profiles/): the best G gives every wavefront about two
+  // window-shares of work (n_windows * G ~ 2 x the chip's 4096 wavefronts) and is never 1 -- with one
+  // wavefront per window the slowest wavefronts finish late (6.68 against 6.90 TB/s at 8192 windows).
+  // A wavefront should also get at least ~8 KiB of a window.
   int g = 16;
   const uint64_t want_waves = (uint64_t)num_cus * kWaves;
-  while (g > 1 && n_windows * (uint64_t)(g / 2) >= want_waves) g >>= 1;
+  while (g > 2 && n_windows * (uint64_t)(g / 2) >= 2 * want_waves) g >>= 1;
   while (g > 1 && (uint64_t)bpc < (uint64_t)g * 8192u) g >>= 1;
   return g;
 }
