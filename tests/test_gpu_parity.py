@@ -480,3 +480,21 @@ def test_cpp_host_mirror_standalone(gpu):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all passed" in r.stdout
+
+
+# ------------------------------------------------------------------ every CRC kernel variant on random shapes
+
+@pytest.mark.parametrize("env", [{"OZCS_CRC_LPW": "64", "OZCS_CRC_GROUP": g} for g in ("1", "2", "4", "8", "16")] +
+                         [{"OZCS_CRC_LPW": l} for l in ("4", "8", "16", "32")],
+                         ids=lambda e: "-".join("%s%s" % (k[9:], v) for k, v in e.items()))
+def test_forced_kernel_variants_random_shapes(gpu, env):
+    # the launcher's heuristics normally pick the variant; here each one must be right on ANY shape
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "variant_check.py"), "7"], env=e,
+                       capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
