@@ -4,7 +4,10 @@ bytes-per-checksum window).
   native    ctypes view of the C-ABI HIP library (csrc/libozcs.so, include/ozone_checksum.h)
   checksum  host-side mirror of the reference interface: Checksum, ChecksumData,
             OzoneChecksumException, ChecksumType (hadoop-hdds/common/.../ozone/common/)
+  read_path the validator and boundary arithmetic of ChunkInputStream around the verify call
+  scrubber  the datanode scrubber's per-chunk check (KeyValueContainerCheck.verifyChecksum), batched
 """
 from . import native  # noqa: F401
 from .checksum import (Checksum, ChecksumData, ChecksumType,  # noqa: F401
                        OzoneChecksumException)
+from . import read_path, scrubber  # noqa: F401,E402
