@@ -25,7 +25,7 @@ struct DigestLaunch {
   unsigned long long* first_mismatch;
 };
 
-hipError_t digest_launch(const DigestLaunch& p, int mode, hipStream_t stream);
+hipError_t digest_launch(const DigestLaunch& p, int mode, int num_cus, hipStream_t stream);
 
 // Unrelated chunks hashed by one launch (compute only); the list travels in the kernel arguments.
 constexpr int kMaxDigestJobs = 96;
@@ -42,6 +42,6 @@ struct DigestJobList {
   uint32_t n_windows;
   int algo;
 };
-hipError_t digest_launch_jobs(const DigestJobList& p, hipStream_t stream);
+hipError_t digest_launch_jobs(const DigestJobList& p, int num_cus, hipStream_t stream);
 
 }  // namespace ozcs

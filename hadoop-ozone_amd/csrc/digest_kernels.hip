@@ -14,6 +14,7 @@
 // registers.  The kernels are integer-ALU bound, not HBM bound.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "crc_kernels.h"  // kModeCompute / kModeVerify
 #include "digest_kernels.h"
@@ -115,25 +116,27 @@ struct Md5 {
 constexpr int kLanes = 64;
 constexpr int kRowBytes = 80;  // 64-byte block + 16 bytes of pad per window slot
 
-// Hashes this lane's window [start, start+len) (nothing when !valid); h receives the digest words in
-// output byte order.  Must be called by all 64 lanes of the one-wavefront workgroup together.
-template <class H>
-__device__ __forceinline__ void digest_core(char* stage, int lane, bool valid, uint64_t start, uint32_t len, uint32_t* h) {
-  const uint32_t nblk = valid ? (uint32_t)(((uint64_t)len + 8) / 64 + 1) : 0u;  // data + padding blocks
-
-  // loader role: for instruction i this lane fetches piece (lane & 3) of slot 16*i + (lane >> 2)
+// Loader role of a wavefront: for instruction i a lane fetches 16-byte piece (lane & 3) of the current
+// 64-byte block of window slot 16*i + (lane >> 2), so that one instruction reads 16 windows x 64 B.
+struct BlockLoader {
   uint64_t lstart[4];
   uint32_t llen[4];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int slot = 16 * i + (lane >> 2);
-    const uint32_t lo = __shfl((uint32_t)start, slot, 64), hi = __shfl((uint32_t)(start >> 32), slot, 64);
-    lstart[i] = ((uint64_t)hi << 32) | lo;
-    llen[i] = __shfl(valid ? len : 0u, slot, 64);
-  }
-  const uint32_t piece = (lane & 3) * 16;
+  uint32_t piece;
+  int lane;
 
-  auto fetch = [&](uint32_t blk, u32x4* r) {
+  __device__ __forceinline__ void init(int lane_, bool valid, uint64_t start, uint32_t len) {
+    lane = lane_;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int slot = 16 * i + (lane >> 2);
+      const uint32_t lo = __shfl((uint32_t)start, slot, 64), hi = __shfl((uint32_t)(start >> 32), slot, 64);
+      lstart[i] = ((uint64_t)hi << 32) | lo;
+      llen[i] = __shfl(valid ? len : 0u, slot, 64);
+    }
+    piece = (lane & 3) * 16;
+  }
+
+  __device__ __forceinline__ void fetch(uint32_t blk, u32x4* r) const {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const uint64_t o = (uint64_t)blk * 64 + piece;
@@ -150,53 +153,170 @@ __device__ __forceinline__ void digest_core(char* stage, int lane, bool valid, u
       }
       r[i] = v;
     }
-  };
+  }
 
-  H::init(h);
-
-  u32x4 r[4];
-  fetch(0, r);
-  for (uint32_t blk = 0; __ballot(blk < nblk) != 0ull; blk++) {
-    __syncthreads();  // the previous block has been read by every owner
+  // Parks the fetched pieces in the 80-byte rows of `stage` (row = window slot).
+  __device__ __forceinline__ void park(char* stage, const u32x4* r) const {
 #pragma unroll
     for (int i = 0; i < 4; i++)
       *reinterpret_cast<u32x4*>(stage + (16 * i + (lane >> 2)) * kRowBytes + piece) = r[i];
-    __syncthreads();
-    fetch(blk + 1, r);  // in flight during the compression below
+  }
+};
 
+// Owner role: reads this lane's own 64-byte block from `stage` as 16 words in the hash's word order and
+// builds the padding (0x80, zeros, bit length) where the message ends.
+template <class H>
+__device__ __forceinline__ void block_words(const char* stage, int lane, uint32_t blk, uint32_t len, uint32_t nblk,
+                                            uint32_t* w) {
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(stage + lane * kRowBytes + 16 * j);
+    w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
+  }
+  if (H::kBigEndian) {
+#pragma unroll
+    for (int j = 0; j < 16; j++) w[j] = __builtin_bswap32(w[j]);
+  }
+  const int64_t rem = (int64_t)len - (int64_t)blk * 64;  // message bytes from this block on
+  if (rem < 64) {  // this block holds the end of the message and/or padding
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const int64_t rj = rem - 4 * j;  // message bytes in word j
+      if (rj >= 4) continue;
+      if (rj < 0) { w[j] = 0; continue; }
+      const int sh = 8 * (int)rj;
+      if (H::kBigEndian) w[j] = (rj == 0 ? 0u : (w[j] & (0xFFFFFFFFu << (32 - sh)))) | (0x80000000u >> sh);
+      else w[j] = (w[j] & ((1u << sh) - 1u)) | (0x80u << sh);
+    }
+    if (blk + 1 == nblk) {
+      const uint64_t bits = (uint64_t)len * 8;
+      if (H::kBigEndian) { w[14] = (uint32_t)(bits >> 32); w[15] = (uint32_t)bits; }
+      else { w[14] = (uint32_t)bits; w[15] = (uint32_t)(bits >> 32); }
+    }
+  }
+}
+
+__device__ __forceinline__ uint32_t num_blocks(bool valid, uint32_t len) {
+  return valid ? (uint32_t)(((uint64_t)len + 8) / 64 + 1) : 0u;  // data + padding blocks
+}
+
+// Hashes this lane's window [start, start+len) (nothing when !valid); h receives the digest words in
+// output byte order.  Must be called by all 64 lanes of the one-wavefront workgroup together.
+template <class H>
+__device__ __forceinline__ void digest_core(char* stage, int lane, bool valid, uint64_t start, uint32_t len, uint32_t* h) {
+  const uint32_t nblk = num_blocks(valid, len);
+  BlockLoader ld;
+  ld.init(lane, valid, start, len);
+  H::init(h);
+  u32x4 r[4];
+  ld.fetch(0, r);
+  for (uint32_t blk = 0; __ballot(blk < nblk) != 0ull; blk++) {
+    __syncthreads();  // the previous block has been read by every owner
+    ld.park(stage, r);
+    __syncthreads();
+    ld.fetch(blk + 1, r);  // in flight during the compression below
     uint32_t w[16];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const u32x4 v = *reinterpret_cast<const u32x4*>(stage + lane * kRowBytes + 16 * j);
-      w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
-    }
-    if (H::kBigEndian) {
-#pragma unroll
-      for (int j = 0; j < 16; j++) w[j] = __builtin_bswap32(w[j]);
-    }
-    const int64_t rem = (int64_t)len - (int64_t)blk * 64;  // message bytes from this block on
-    if (rem < 64) {  // this block holds the end of the message and/or padding
-#pragma unroll
-      for (int j = 0; j < 16; j++) {
-        const int64_t rj = rem - 4 * j;  // message bytes in word j
-        if (rj >= 4) continue;
-        if (rj < 0) { w[j] = 0; continue; }
-        const int sh = 8 * (int)rj;
-        if (H::kBigEndian) w[j] = (rj == 0 ? 0u : (w[j] & (0xFFFFFFFFu << (32 - sh)))) | (0x80000000u >> sh);
-        else w[j] = (w[j] & ((1u << sh) - 1u)) | (0x80u << sh);
-      }
-      if (blk + 1 == nblk) {
-        const uint64_t bits = (uint64_t)len * 8;
-        if (H::kBigEndian) { w[14] = (uint32_t)(bits >> 32); w[15] = (uint32_t)bits; }
-        else { w[14] = (uint32_t)bits; w[15] = (uint32_t)(bits >> 32); }
-      }
-    }
+    block_words<H>(stage, lane, blk, len, nblk, w);
     if (blk < nblk) H::compress(h, w);
   }
   if (H::kBigEndian) {
 #pragma unroll
     for (int j = 0; j < H::kWords; j++) h[j] = __builtin_bswap32(h[j]);
   }
+}
+
+// SHA-256 with the message schedule and the compression function on two wavefronts of one workgroup.
+// A lone wavefront issues one VALU instruction per ~4.6 cycles however much instruction-level parallelism
+// it has, so when windows are too few to put two wavefronts on every SIMD the only way to use more of the
+// chip is more wavefronts per window set.  The schedule W[16..63] of a block depends on the block alone,
+// not on the chain: wavefront 0 loads blocks, builds the padding and expands W (about 40 % of the
+// instructions), wavefront 1 runs the 64 rounds.  W travels through LDS, 16 KiB per block, double-buffered,
+// one workgroup barrier per block: while wavefront 1 compresses block b-1, wavefront 0 expands block b.
+// A workgroup is four wavefronts = two such pairs (window sets 0 and 1): the hardware spreads the four
+// wavefronts of one workgroup over the CU's four SIMDs, which two separate two-wavefront workgroups on one
+// CU do not get (measured: 53 ms instead of 34 ms per 1 MiB window).  Wavefronts 0/1 expand sets 0/1,
+// wavefronts 2/3 compress them; lane l of wavefronts s and s+2 owns the same window.  h is valid in
+// wavefronts 2 and 3 only.  `stage`, `wbuf` and `sync` are this workgroup's; all 256 threads call.
+constexpr int kWBufBytes = 64 * kLanes * 4;
+constexpr int kSplitThreads = 4 * kLanes;
+constexpr int kSplitWindows = 2 * kLanes;  // windows per workgroup
+
+__device__ __forceinline__ void sha256_split_core(char* stage_all, char* wbuf_all, uint32_t* sync, int tid, bool valid,
+                                                  uint64_t start, uint32_t len, uint32_t* h) {
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int set = wave & 1;
+  const bool compressor = wave >= 2;
+  char* stage = stage_all + set * (kLanes * kRowBytes);
+  char* wbuf = wbuf_all + set * (2 * kWBufBytes);
+  const uint32_t nblk = num_blocks(valid, len);
+  uint32_t nmax = nblk;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t other = __shfl_xor(nmax, o, 64);
+    nmax = other > nmax ? other : nmax;
+  }
+  if (lane == 0) sync[wave] = nmax;  // every wavefront must pass the same number of barriers
+  __syncthreads();
+  nmax = sync[0] > sync[1] ? sync[0] : sync[1];
+  BlockLoader ld;
+  u32x4 r[4];
+  if (!compressor) {
+    ld.init(lane, valid, start, len);
+    ld.fetch(0, r);
+  }
+  Sha256::init(h);
+  for (uint32_t blk = 0; blk <= nmax; blk++) {
+    __syncthreads();  // W of block blk-1 is complete; the buffer of block blk-2 has been consumed
+    if (!compressor) {
+      if (blk < nmax) {
+        ld.park(stage, r);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // stage is private to this wavefront; its DS
+        __builtin_amdgcn_wave_barrier();                        // operations execute in issue order
+        ld.fetch(blk + 1, r);
+        uint32_t w[16];
+        block_words<Sha256>(stage, lane, blk, len, nblk, w);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        char* dst = wbuf + (blk & 1) * kWBufBytes + lane * 16;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          *reinterpret_cast<u32x4*>(dst + q * (kLanes * 16)) = (u32x4){w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
+#pragma unroll
+        for (int i = 16; i < 64; i++) {
+          const uint32_t w15 = w[(i + 1) & 15], w2 = w[(i + 14) & 15];
+          const uint32_t s0 = xor3(rotr(w15, 7), rotr(w15, 18), w15 >> 3);
+          const uint32_t s1 = xor3(rotr(w2, 17), rotr(w2, 19), w2 >> 10);
+          w[i & 15] = w[i & 15] + s0 + w[(i + 9) & 15] + s1;
+          if ((i & 3) == 3) {
+            const int b = i & 12;  // ring position of the four words just completed
+            *reinterpret_cast<u32x4*>(dst + (i >> 2) * (kLanes * 16)) = (u32x4){w[b], w[b + 1], w[b + 2], w[b + 3]};
+          }
+        }
+      }
+    } else if (blk >= 1 && blk - 1 < nblk) {
+      const char* src = wbuf + ((blk - 1) & 1) * kWBufBytes + lane * 16;
+      uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(src + q * (kLanes * 16));
+        const uint32_t wq[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const uint32_t S1 = xor3(rotr(e, 6), rotr(e, 11), rotr(e, 25));
+          const uint32_t ch = (e & f) ^ (~e & g);
+          const uint32_t t1 = hh + S1 + ch + kK256[4 * q + k] + wq[k];
+          const uint32_t S0 = xor3(rotr(a, 2), rotr(a, 13), rotr(a, 22));
+          const uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
+          const uint32_t t2 = S0 + mj;
+          hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+        }
+      }
+      h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; j++) h[j] = __builtin_bswap32(h[j]);
 }
 
 template <class H>
@@ -273,10 +393,91 @@ __global__ __launch_bounds__(kLanes) void digest_jobs_kernel(const DigestJobList
   if (valid) store_digest<H>(out, h);
 }
 
+// The split SHA-256 forms of the two kernels above (workgroup = 256 threads = 128 windows).
+template <int MODE>
+__global__ __launch_bounds__(kSplitThreads) void sha256_split_windows_kernel(const DigestLaunch p) {
+  __shared__ __attribute__((aligned(16))) char stage[2 * kLanes * kRowBytes];
+  __shared__ __attribute__((aligned(16))) char wbuf[4 * kWBufBytes];
+  __shared__ uint32_t sync[4];
+  const int tid = threadIdx.x;
+  const uint64_t g = (uint64_t)blockIdx.x * kSplitWindows + (tid & (kSplitWindows - 1));
+  const bool valid = g < p.n_windows;
+  uint64_t chunk = 0, wi = 0, start = 0;
+  uint32_t len = 0;
+  if (valid) {
+    chunk = g / p.wpc;
+    wi = g - chunk * p.wpc;
+    const uint64_t woff = wi * (uint64_t)p.bpc;
+    const uint64_t left = p.chunk_len - woff;
+    len = (uint32_t)(left < p.bpc ? left : p.bpc);
+    start = reinterpret_cast<uintptr_t>(p.data) + chunk * p.chunk_stride + woff;
+  }
+  uint32_t h[8];
+  sha256_split_core(stage, wbuf, sync, tid, valid, start, len, h);
+  if (!valid || tid < kSplitWindows) return;
+  if (MODE == kModeCompute) {
+    store_digest<Sha256>(p.sums + g * 32, h);
+  } else {
+    const uint64_t si = p.start_index + wi;
+    bool bad = si >= p.n_expected;
+    if (!bad) {
+      const uint8_t* ex = p.expected + chunk * p.expected_stride + si * 32;
+#pragma unroll
+      for (int j = 0; j < 32; j++) bad |= ex[j] != (uint8_t)(h[j >> 2] >> (8 * (j & 3)));
+    }
+    if (bad) atomicMin(p.first_mismatch + chunk, (unsigned long long)wi);
+  }
+}
+
+__global__ __launch_bounds__(kSplitThreads) void sha256_split_jobs_kernel(const DigestJobList p) {
+  __shared__ __attribute__((aligned(16))) char stage[2 * kLanes * kRowBytes];
+  __shared__ __attribute__((aligned(16))) char wbuf[4 * kWBufBytes];
+  __shared__ uint32_t sync[4];
+  const int tid = threadIdx.x;
+  const uint32_t g = blockIdx.x * kSplitWindows + (tid & (kSplitWindows - 1));
+  const bool valid = g < p.n_windows;
+  uint64_t start = 0;
+  uint32_t len = 0;
+  uint8_t* out = nullptr;
+  if (valid) {
+    uint32_t j = 0;
+    while (j + 1 < p.n_jobs && p.jobs[j + 1].first_window <= g) j++;
+    const DigestJob& job = p.jobs[j];
+    const uint64_t wi = g - job.first_window;
+    const uint64_t woff = wi * (uint64_t)job.bpc;
+    const uint64_t left = job.len - woff;
+    len = (uint32_t)(left < job.bpc ? left : job.bpc);
+    start = reinterpret_cast<uintptr_t>(job.data) + woff;
+    out = job.sums + wi * 32;
+  }
+  uint32_t h[8];
+  sha256_split_core(stage, wbuf, sync, tid, valid, start, len, h);
+  if (valid && tid >= kSplitWindows) store_digest<Sha256>(out, h);
+}
+
+// Tuning override for experiments (read once): OZCS_SHA_SPLIT = 0 never, 1 always; unset = by window count.
+const int g_sha_split = getenv("OZCS_SHA_SPLIT") ? atoi(getenv("OZCS_SHA_SPLIT")) : -1;
+
+// The split form pays while SIMDs are idle.  These integer instructions issue at one wave64 instruction
+// per 4 cycles per SIMD, so a single wavefront already saturates its SIMD: with up to one split workgroup
+// per CU (128 windows) every window set gets two SIMDs instead of one (34 ms instead of 50 ms per 1 MiB
+// window); beyond that the one-wavefront form executes fewer instructions in total.
+bool use_sha_split(uint64_t n_windows, int num_cus) {
+  if (g_sha_split == 0) return false;
+  if (g_sha_split == 1) return true;
+  return n_windows <= (uint64_t)num_cus * kSplitWindows;
+}
+
 }  // namespace
 
-hipError_t digest_launch(const DigestLaunch& p, int mode, hipStream_t stream) {
+hipError_t digest_launch(const DigestLaunch& p, int mode, int num_cus, hipStream_t stream) {
   if (p.n_windows == 0) return hipSuccess;
+  if (p.algo == kAlgoSha256 && use_sha_split(p.n_windows, num_cus)) {
+    const uint64_t nb = (p.n_windows + kSplitWindows - 1) / kSplitWindows;
+    if (mode == kModeCompute) sha256_split_windows_kernel<kModeCompute><<<dim3((unsigned)nb), dim3(kSplitThreads), 0, stream>>>(p);
+    else sha256_split_windows_kernel<kModeVerify><<<dim3((unsigned)nb), dim3(kSplitThreads), 0, stream>>>(p);
+    return hipGetLastError();
+  }
   const uint64_t blocks = (p.n_windows + kLanes - 1) / kLanes;
   if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
   const dim3 grid((unsigned)blocks), block(kLanes);
@@ -290,8 +491,12 @@ hipError_t digest_launch(const DigestLaunch& p, int mode, hipStream_t stream) {
   return hipGetLastError();
 }
 
-hipError_t digest_launch_jobs(const DigestJobList& p, hipStream_t stream) {
+hipError_t digest_launch_jobs(const DigestJobList& p, int num_cus, hipStream_t stream) {
   if (p.n_windows == 0 || p.n_jobs == 0) return hipSuccess;
+  if (p.algo == kAlgoSha256 && use_sha_split(p.n_windows, num_cus)) {
+    sha256_split_jobs_kernel<<<dim3((p.n_windows + kSplitWindows - 1) / kSplitWindows), dim3(kSplitThreads), 0, stream>>>(p);
+    return hipGetLastError();
+  }
   const dim3 grid((p.n_windows + kLanes - 1) / kLanes), block(kLanes);
   if (p.algo == kAlgoSha256) digest_jobs_kernel<Sha256><<<grid, block, 0, stream>>>(p);
   else digest_jobs_kernel<Md5><<<grid, block, 0, stream>>>(p);

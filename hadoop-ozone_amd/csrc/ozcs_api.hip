@@ -164,7 +164,7 @@ int launch_windows(const DeviceInfo& dev, int type, uint32_t bpc, const void* d_
     p.n_expected = n_expected;
     p.start_index = start_index;
     p.first_mismatch = d_first_mismatch;
-    e = digest_launch(p, mode, stream);
+    e = digest_launch(p, mode, dev.num_cus, stream);
   }
   if (e != hipSuccess) return fail_hip(e, "kernel launch");
   s_launches.fetch_add(1, std::memory_order_relaxed);
@@ -271,7 +271,7 @@ static void batch_on_device(int device, ozcs_chunk* chunks, uint32_t lo, uint32_
         jl.algo = algo;
         auto launch = [&]() {
           if (jl.n_jobs && e == hipSuccess) {
-            e = digest_launch_jobs(jl, c->stream);
+            e = digest_launch_jobs(jl, dev->num_cus, c->stream);
             s_launches.fetch_add(1, std::memory_order_relaxed);
             s_windows.fetch_add(jl.n_windows, std::memory_order_relaxed);
           }

@@ -103,7 +103,7 @@ int flush_deferred(ozcs_pipe* p) {
       hipError_t e = hipSuccess;
       for (int t : batch)
         if (e == hipSuccess) e = hipStreamWaitEvent(p->s_digest, p->slots[t].copied, 0);
-      if (e == hipSuccess) e = digest_launch_jobs(jl, p->s_digest);
+      if (e == hipSuccess) e = digest_launch_jobs(jl, p->dev.num_cus, p->s_digest);
       Slot& lead = p->slots[batch[0]];
       if (e == hipSuccess) e = hipEventRecord(lead.hashed, p->s_digest);
       if (e == hipSuccess) e = hipStreamWaitEvent(p->s_digest_d2h, lead.hashed, 0);

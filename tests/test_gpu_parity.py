@@ -498,3 +498,17 @@ def test_forced_kernel_variants_random_shapes(gpu, env):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "variant_check.py"), "7"], env=e,
                        capture_output=True, text=True, timeout=170)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("split", ["0", "1"])
+def test_sha256_one_and_two_wavefront_forms(gpu, split):
+    # the launcher picks the form by window count; both must be right on any shape (MD5 rides along)
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    e = dict(os.environ)
+    e["OZCS_SHA_SPLIT"] = split
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "variant_check.py"), "11", "digests"], env=e,
+                       capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
