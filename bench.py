@@ -24,6 +24,7 @@ MIB = 1 << 20
 BLOCK_BYTES = 256 * MIB   # ozone.scm.block.size, OzoneConfigKeys.java:115-116
 CHUNK_BYTES = 4 * MIB     # ozone.scm.chunk.size / stream buffer, OzoneClientConfig.java:50-55
 HBM_PEAK_GBPS = 8000.0    # MI355X HBM3E datasheet peak
+MEASURED_NT_READ_GBPS = 6980.0  # pure non-temporal streaming read in the kernel's access pattern (profiles/r01_hbm_read_microbench.log)
 
 
 def shard_blocks(total_blocks, rank, world):
@@ -84,6 +85,9 @@ def main():
     ap.add_argument("--bpc", type=int, default=MIB)
     ap.add_argument("--mode", default="compute", choices=["compute", "verify"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --device-index 0 rehearses the multi-rank path on a one-GPU box")
+    ap.add_argument("--device-index", type=int, default=-1, help="GPU of this rank (default: LOCAL_RANK)")
     args = ap.parse_args()
 
     import torch
@@ -98,10 +102,15 @@ def main():
             sys.exit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (there is no CPU path in this library)")
+    if args.device_index >= 0:
+        local_rank = args.device_index
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     L = native.lib()
     native.check(L.ozcs_init(1 << local_rank))
@@ -156,7 +165,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
@@ -180,6 +189,7 @@ def main():
             "config": {"workload": workload, "blocks_per_gpu": args.blocks, "chunk_bytes": CHUNK_BYTES,
                        "bytes_per_checksum": args.bpc, "windows_per_gpu": n_windows, "sharding": "by block, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "peak_measured_nt_read": MEASURED_NT_READ_GBPS,
                          "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": load_profile_traffic("%s-%d-%d" % (args.type, args.bpc, args.blocks)),
                          "kernel_ms_avg": round(avg_kernel_s * 1e3, 4), "kernel_ms_min": round(min(kernel_ms), 4),

@@ -512,3 +512,27 @@ def test_sha256_one_and_two_wavefront_forms(gpu, split):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "variant_check.py"), "11", "digests"], env=e,
                        capture_output=True, text=True, timeout=170)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_bench_two_ranks_rehearsal(gpu):
+    # the launch line the driver uses for N > 1, rehearsed on one GPU: gloo for the barrier / MAX, both ranks on GPU 0
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--blocks", "2", "--dist-backend", "gloo", "--device-index", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=170, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1   # rank 0 alone prints
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0 and "cpu_baseline" not in rec
+    assert rec["config"]["blocks_per_gpu"] == 2
