@@ -553,4 +553,59 @@ int ozcs_compute_batch(ozcs_chunk* chunks, uint32_t n_chunks) {
   return OZCS_OK;
 }
 
+int ozcs_verify_batch(ozcs_vchunk* v, uint32_t n_chunks) {
+  if (n_chunks == 0) return OZCS_OK;
+  if (!v) return fail(OZCS_EINVAL, "null chunk list");
+  // Hash everything that needs hashing through the batched compute path into scratch digests, then compare
+  // on the host: digests are a few bytes per window, the hashing is the work.
+  std::vector<ozcs_chunk> jobs;
+  std::vector<uint32_t> owner;
+  std::vector<std::vector<uint8_t>> sums;
+  jobs.reserve(n_chunks);
+  for (uint32_t i = 0; i < n_chunks; i++) {
+    ozcs_vchunk& c = v[i];
+    c.first_mismatch = -1;
+    c.status = check_type_bpc(c.type, c.bpc);
+    if (c.status != OZCS_OK || c.type == OZCS_NONE) continue;  // NONE: Checksum.java:241-244
+    const uint64_t n = ozcs_num_checksums(c.len, c.bpc);
+    if (c.n_expected == 0) { c.status = fail(OZCS_EEMPTY, "Original checksumData has no checksums"); continue; }
+    if (n == 0) { c.status = fail(OZCS_EEMPTY, "Computed checksumData has no checksums"); continue; }
+    if (!c.data || !c.expected) { c.status = fail(OZCS_EINVAL, "null pointer in chunk %u", i); continue; }
+    sums.emplace_back((size_t)(n * ozcs_digest_size(c.type)));
+    ozcs_chunk j{};
+    j.data = c.data;
+    j.len = c.len;
+    j.sums = sums.back().data();
+    j.sums_cap = sums.back().size();
+    j.bpc = c.bpc;
+    j.type = c.type;
+    jobs.push_back(j);
+    owner.push_back(i);
+  }
+  if (!jobs.empty()) (void)ozcs_compute_batch(jobs.data(), (uint32_t)jobs.size());
+  for (size_t k = 0; k < jobs.size(); k++) {
+    ozcs_vchunk& c = v[owner[k]];
+    if (jobs[k].status != OZCS_OK) { c.status = jobs[k].status; continue; }
+    const size_t ds = ozcs_digest_size(c.type);
+    const uint8_t* ex = static_cast<const uint8_t*>(c.expected);
+    const uint8_t* got = sums[k].data();
+    for (uint64_t i = 0; i < jobs[k].n_sums; i++) {  // ChecksumData.java:135-141
+      if (c.start_index + i >= c.n_expected) {
+        c.status = fail(OZCS_ERANGE, "Computed checksum has %llu number of checksums. Original checksum has %llu number "
+                        "of checksums starting from index %llu", (unsigned long long)jobs[k].n_sums,
+                        (unsigned long long)(c.n_expected > c.start_index ? c.n_expected - c.start_index : 0),
+                        (unsigned long long)c.start_index);
+        break;
+      }
+      if (memcmp(ex + (c.start_index + i) * ds, got + i * ds, ds) != 0) {
+        c.first_mismatch = (int64_t)i;
+        break;
+      }
+    }
+  }
+  for (uint32_t i = 0; i < n_chunks; i++)
+    if (v[i].status != OZCS_OK) return v[i].status;
+  return OZCS_OK;
+}
+
 }  // extern "C"

@@ -21,6 +21,13 @@ class OzcsChunk(ctypes.Structure):
                 ("n_sums", ctypes.c_uint64), ("status", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
+class OzcsVChunk(ctypes.Structure):
+    _fields_ = [("data", ctypes.c_void_p), ("len", ctypes.c_uint64), ("expected", ctypes.c_void_p),
+                ("n_expected", ctypes.c_uint64), ("start_index", ctypes.c_uint64), ("bpc", ctypes.c_uint32),
+                ("type", ctypes.c_int32), ("first_mismatch", ctypes.c_int64), ("status", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
 class OzcsStats(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint64) for n in
                 ("calls", "bytes_hashed", "windows", "h2d_bytes", "d2h_bytes", "kernel_launches")]
@@ -42,6 +49,7 @@ SIGNATURES = {
                                    ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64,
                                    ctypes.POINTER(ctypes.c_int64)]),
     "ozcs_compute_batch": (ctypes.c_int, [ctypes.POINTER(OzcsChunk), ctypes.c_uint32]),
+    "ozcs_verify_batch": (ctypes.c_int, [ctypes.POINTER(OzcsVChunk), ctypes.c_uint32]),
     "ozcs_compute_device": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p,
                                            ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p,
                                            ctypes.c_uint64, ctypes.c_void_p]),

@@ -76,3 +76,61 @@ def verifyChecksum(block_id, chunk_name, chunk_offset, chunk_len, checksum_data,
         raise OzoneChecksumException("Inconsistent read for chunk=%s expected length=%d actual length=%d for block %s"
                                      % (chunk_name, chunk_len, n_read, block_id))
     return n_read
+
+
+def verifyBlock(block_id, chunks, layout, throttler=None, canceler=None):
+    """The `for chunk in block.getChunks()` loop of KeyValueContainerCheck.scanData (:235-257) with ONE
+    ozcs_verify_batch call for all chunks instead of one checksum call per window.
+
+    chunks: list of (chunk_name, chunk_offset, chunk_len, checksum_data, chunk_file).  Chunks are read and
+    throttled in order; the first chunk (in order) that fails raises what verifyChecksum would raise for it.
+    Returns the number of bytes read."""
+    import ctypes
+    import numpy as np
+    reads = []
+    for name, off, ln, cd, path in chunks:
+        sums = cd.getChecksums()
+        bpc = cd.getBytesPerChecksum()
+        want = len(sums) * bpc
+        if layout == FILE_PER_BLOCK and sums and ln % bpc != 0:
+            want = (len(sums) - 1) * bpc + ln % bpc
+        with open(path, "rb") as f:
+            if layout == FILE_PER_BLOCK:
+                f.seek(off)
+            data = f.read(want) if want else b""
+        nwin = (len(data) + bpc - 1) // bpc if bpc else 0
+        if throttler is not None:
+            for i in range(nwin):
+                throttler(min(bpc, len(data) - i * bpc), canceler)
+        reads.append((np.frombuffer(data, dtype=np.uint8), b"".join(sums[:nwin]), nwin))
+    n = len(chunks)
+    arr = (native.OzcsVChunk * n)()
+    for i, ((name, off, ln, cd, path), (data, stored, nwin)) in enumerate(zip(chunks, reads)):
+        t = cd.getChecksumType()
+        arr[i].type = int(t) if nwin else int(ChecksumType.NONE)   # nothing read: only the length check applies
+        arr[i].bpc = cd.getBytesPerChecksum()
+        arr[i].data = data.ctypes.data if data.size else None
+        arr[i].len = data.size
+        arr[i].expected = ctypes.cast(ctypes.c_char_p(stored), ctypes.c_void_p).value
+        arr[i].n_expected = nwin
+        arr[i].start_index = 0
+    rc = native.lib().ozcs_verify_batch(arr, n)
+    total = 0
+    for i, ((name, off, ln, cd, path), (data, stored, nwin)) in enumerate(zip(chunks, reads)):
+        if arr[i].status != native.OK:
+            if rc in (native.ENODEV, native.EHIP, native.ENOMEM):
+                native.check(arr[i].status)
+            raise OzoneChecksumException("verify failed for chunk %s: status %d" % (name, arr[i].status))
+        first = arr[i].first_mismatch
+        if first >= 0:
+            t, bpc = cd.getChecksumType(), cd.getBytesPerChecksum()
+            ds = native.DIGEST_SIZE[int(t)]
+            actual = native.compute(int(t), bpc, data[first * bpc:(first + 1) * bpc])[:ds]
+            raise OzoneChecksumException(
+                "Inconsistent read for chunk=%s checksum item %d expected checksum %s actual checksum %s for block %s"
+                % (chunk_info_str(name, off, ln), first, _java_bytes(cd.getChecksums()[first]), _java_bytes(actual), block_id))
+        if data.size != ln:
+            raise OzoneChecksumException("Inconsistent read for chunk=%s expected length=%d actual length=%d for block %s"
+                                         % (name, ln, data.size, block_id))
+        total += data.size
+    return total

@@ -117,6 +117,26 @@ typedef struct ozcs_chunk {
  * windows); there is no inter-device traffic.  Returns the first non-OK per-chunk status, or OZCS_OK. */
 OZCS_API int ozcs_compute_batch(ozcs_chunk* chunks, uint32_t n_chunks);
 
+typedef struct ozcs_vchunk {
+  const void* data;        /* in : host pointer of the bytes read                                 */
+  uint64_t len;            /* in                                                                   */
+  const void* expected;    /* in : host pointer of the chunk's stored digests, back to back        */
+  uint64_t n_expected;     /* in : how many stored digests                                         */
+  uint64_t start_index;    /* in : stored[start_index + i] is compared with computed[i]            */
+  uint32_t bpc;            /* in                                                                   */
+  int32_t type;            /* in : enum ozcs_type                                                  */
+  int64_t first_mismatch;  /* out: first failing i, or -1                                          */
+  int32_t status;          /* out: OZCS_OK / OZCS_ERANGE / OZCS_EEMPTY / ... exactly as ozcs_verify */
+  int32_t reserved;
+} ozcs_vchunk;
+
+/* ozcs_verify for many chunks in one call: the loop of KeyValueContainerCheck.verifyChecksum
+ * (hadoop-hdds/container-service/src/main/java/org/apache/hadoop/ozone/container/keyvalue/
+ * KeyValueContainerCheck.java:262-322) over all chunks of a block or container, hashed in bulk (sharded over
+ * the devices like ozcs_compute_batch).  Per chunk the outcome is the one ozcs_verify would give.  Returns
+ * the first per-chunk status that is not OZCS_OK, or OZCS_OK (a mismatch is not an error). */
+OZCS_API int ozcs_verify_batch(ozcs_vchunk* chunks, uint32_t n_chunks);
+
 /* ---- device-resident: pointers are device memory on `device`, work is queued on hip_stream ----
  * (hip_stream is a hipStream_t passed as void*; NULL = the default stream.)  No implicit
  * synchronisation: results are valid once the stream reaches the end of the call's work. */

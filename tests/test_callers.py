@@ -95,3 +95,71 @@ def test_scrubber_like_TestKeyValueContainerCheck(tmp_path, layout):
     open(files[0], "wb").write(bytes(raw))
     with pytest.raises(OzoneChecksumException, match="checksum item 1 expected"):
         scrubber.verifyChecksum("blk1", "c0", offsets[0], chunk_len, cds[0], str(files[0]), layout)
+
+
+@pytest.mark.gpu
+def test_scrubber_whole_block_in_one_call(tmp_path):
+    # a FILE_PER_BLOCK block of 9 chunks with mixed checksum types, verified by one ozcs_verify_batch
+    chunk_len, n_chunks = 200000, 9
+    types = [(ChecksumType.CRC32, 65536), (ChecksumType.SHA256, 2048), (ChecksumType.CRC32C, 16384), (ChecksumType.MD5, 100000)]
+    datas = [oracle.splitmix64(70 + i, chunk_len).tobytes() for i in range(n_chunks)]
+    path = tmp_path / "7.block"
+    path.write_bytes(b"".join(datas))
+    chunks = []
+    for i, d in enumerate(datas):
+        t, bpc = types[i % 4]
+        cd = ChecksumData(t, bpc, [oracle.compute(int(t), bpc, d[o:o + bpc]) for o in range(0, chunk_len, bpc)])
+        chunks.append(("c%d" % i, i * chunk_len, chunk_len, cd, str(path)))
+    assert scrubber.verifyBlock("blk7", chunks, scrubber.FILE_PER_BLOCK) == n_chunks * chunk_len
+    # corrupt chunk 5 (SHA-256, 2048-byte windows) in its window 40, and chunk 7 too: chunk 5 is reported first
+    raw = bytearray(path.read_bytes())
+    raw[5 * chunk_len + 40 * 2048 + 9] ^= 0x20
+    raw[7 * chunk_len + 3] ^= 0x01
+    path.write_bytes(bytes(raw))
+    with pytest.raises(OzoneChecksumException, match=r"chunk=ChunkInfo\{chunkName='c5, offset=1000000, len=200000\} checksum item 40 expected"):
+        scrubber.verifyBlock("blk7", chunks, scrubber.FILE_PER_BLOCK)
+    # a truncated block file: the last chunk comes up short after its full windows matched
+    path.write_bytes(b"".join(datas)[: 8 * chunk_len + 65536])
+    with pytest.raises(OzoneChecksumException, match="chunk=c8 expected length=200000 actual length=65536 for block blk7"):
+        scrubber.verifyBlock("blk7", chunks, scrubber.FILE_PER_BLOCK)
+
+
+@pytest.mark.gpu
+def test_verify_batch_matches_verify():
+    import ctypes
+    from hadoop_ozone_amd import native
+    L = native.lib()
+    cases = []
+    rng = np.random.default_rng(3)
+    for i in range(24):
+        t = [oracle.CRC32, oracle.CRC32C, oracle.SHA256, oracle.MD5, oracle.NONE][i % 5]
+        bpc = int(rng.choice([20, 1000, 4096, 65536]))
+        ln = int(rng.integers(0, 40 * bpc))
+        d = oracle.splitmix64(300 + i, ln)
+        stored = oracle.compute(t, bpc, d) if t != oracle.NONE else b""
+        mode = i % 6
+        start = 0
+        if mode == 1 and ln:
+            d = d.copy(); d[int(rng.integers(0, ln))] ^= 1            # one flipped bit
+        if mode == 2:
+            stored = stored[: len(stored) // 2 // max(1, native.DIGEST_SIZE[t]) * native.DIGEST_SIZE[t]]   # short stored list
+        if mode == 3:
+            start = 1                                                 # wrong start index
+        cases.append((t, bpc, d, stored, start))
+    arr = (native.OzcsVChunk * len(cases))()
+    keep = []
+    for i, (t, bpc, d, stored, start) in enumerate(cases):
+        ds = native.DIGEST_SIZE[t]
+        arr[i].type, arr[i].bpc = t, bpc
+        arr[i].data, arr[i].len = (d.ctypes.data if d.size else None), d.size
+        sb = ctypes.create_string_buffer(stored, max(1, len(stored)))
+        keep.append(sb)
+        arr[i].expected = ctypes.cast(sb, ctypes.c_void_p).value
+        arr[i].n_expected = (len(stored) // ds) if ds else 0
+        arr[i].start_index = start
+    L.ozcs_verify_batch(arr, len(cases))
+    for i, (t, bpc, d, stored, start) in enumerate(cases):
+        rc, first = native.verify(t, bpc, d, stored, start) if (d.size or t == oracle.NONE or not stored) else (native.EEMPTY, -1)
+        assert (arr[i].status, arr[i].first_mismatch) == (rc, first), (i, t, bpc, d.size, len(stored), start)
+        orc, ofirst = oracle.verify(t, bpc, d, stored, start)
+        assert first == ofirst
