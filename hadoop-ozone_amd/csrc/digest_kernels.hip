@@ -27,8 +27,9 @@ typedef u32x4 u32x4_unaligned __attribute__((aligned(1)));
 typedef const __attribute__((address_space(1))) u32x4_unaligned* gptr_u4u;
 typedef const __attribute__((address_space(1))) uint8_t* gptr_u8;
 
-__device__ __forceinline__ uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
-__device__ __forceinline__ uint32_t rotl(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
+// One v_alignbit_b32 each (the shift-shift-or form is not always folded into it).
+__device__ __forceinline__ uint32_t rotr(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, n); }
+__device__ __forceinline__ uint32_t rotl(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, 32 - n); }
 // Three-input bitwise functions in one instruction (v_bitop3_b32; the table is the function of 0xF0, 0xCC, 0xAA).
 __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
 
