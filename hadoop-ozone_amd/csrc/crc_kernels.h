@@ -16,6 +16,7 @@ struct CrcLaunch {
   uint64_t chunk_stride;
   uint64_t n_windows;  // n_chunks * wpc
   uint64_t wpc;
+  int wpc_shift;  // log2(wpc) when wpc is a power of two, else -1; filled in by crc_launch
   uint32_t bpc;
   int poly_idx;  // 0 = CRC32, 1 = CRC32C
   // compute: 4 big-endian bytes per window at sums + 4*g

@@ -58,15 +58,36 @@ __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
   return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
 }
 
-// x * x^(8*n) mod P through the 16-entry nibble tables of one operator.
-__device__ __forceinline__ uint32_t nib_apply(const char* op_tab, uint32_t x) {
+// x * x^(8*n) mod P through the 16-entry nibble tables of operator `op` (an index into kOpBytes).
+// Index extraction: the eight nibbles, times four, are masked into the bytes of two registers and every
+// LDS address is then ONE v_perm_b32 (byte 0 <- that byte, bytes 1..2 <- the table area's base); the
+// operator's and the nibble's offsets ride in the instruction's immediate offset field.
+__device__ __forceinline__ uint32_t nib_apply(const char* lds, int op, uint32_t x) {
+  const uint32_t m0 = (x << 2) & 0x3c3c3c3cu;  // nibbles 0, 2, 4, 6
+  const uint32_t m1 = (x >> 2) & 0x3c3c3c3cu;  // nibbles 1, 3, 5, 7
+  const uint32_t off = (uint32_t)op * kNibOpBytes;
   uint32_t t[8];
 #pragma unroll
-  for (int q = 0; q < 8; q++) {
-    const uint32_t idx4 = (q == 0) ? ((x << 2) & 0x3cu) : ((x >> (4 * q - 2)) & 0x3cu);
-    t[q] = lds_u32(op_tab, q * 64 + idx4);
+  for (int k = 0; k < 4; k++) {
+    t[2 * k] = lds_u32(lds, __builtin_amdgcn_perm(m0, kNibOff, 0x0c020104u + k) + (off + (2 * k) * 64u));
+    t[2 * k + 1] = lds_u32(lds, __builtin_amdgcn_perm(m1, kNibOff, 0x0c020104u + k) + (off + (2 * k + 1) * 64u));
   }
   return xor3(xor3(t[0], t[1], t[2]), xor3(t[3], t[4], t[5]), t[6] ^ t[7]);
+}
+
+// Value of the lane N places lower in the same row of 16 lanes (0 where there is none): one DPP move.
+template <int N>
+__device__ __forceinline__ uint32_t row_shr(uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x110 + N, 0xf, 0xf, true);
+}
+__device__ __forceinline__ uint32_t lanes_up(uint32_t x, int level) {
+  switch (level) {
+    case 0: return row_shr<1>(x);
+    case 1: return row_shr<2>(x);
+    case 2: return row_shr<4>(x);
+    case 3: return row_shr<8>(x);
+    default: return __shfl_up(x, 1u << level, 64);
+  }
 }
 
 struct Acc4 {
@@ -151,6 +172,30 @@ __device__ __forceinline__ uint4 init_spill(uintptr_t u, uintptr_t s) {
 }
 __device__ __forceinline__ uint4 xor4(uint4 a, uint4 b) { return make_uint4(a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w); }
 
+// The 16-byte unit at u of a window whose start s is 16-byte aligned: a unit lies wholly in front of the
+// window or wholly inside it, and the initial register lands on the first dword of the unit at s.
+__device__ __forceinline__ Acc4 first_unit_aligned(uintptr_t u, uintptr_t s) {
+  Acc4 a = {0, 0, 0, 0};
+  if (u >= s) {
+    const uint4 d = ld16(u);
+    a.a0 = d.x ^ (u == s ? 0xFFFFFFFFu : 0u);
+    a.a1 = d.y;
+    a.a2 = d.z;
+    a.a3 = d.w;
+  }
+  return a;
+}
+
+// Window g -> (chunk, index inside the chunk).  64-bit division is some 150 instructions on this
+// hardware, so the common cases avoid it: a power-of-two window count per chunk, or a batch whose
+// window count fits 32 bits.
+__device__ __forceinline__ void split_window(const CrcLaunch& p, uint64_t g, uint64_t& chunk, uint64_t& wi) {
+  if (p.wpc_shift >= 0) chunk = g >> p.wpc_shift;
+  else if ((p.n_windows >> 32) == 0) chunk = (uint32_t)g / (uint32_t)p.wpc;
+  else chunk = g / p.wpc;
+  wi = g - chunk * p.wpc;
+}
+
 // Builds the LDS tables from the 32-entry operator bases: the four byte tables of operator `main_op` in
 // 32 copies, and the nibble tables of operators 0..kNibOps-1.  All kThreads threads take part.
 __device__ __forceinline__ void build_tables(char* lds, const PolyBasis& pb, int main_op, int tid) {
@@ -211,24 +256,20 @@ __device__ __forceinline__ uint32_t finish_window(uint32_t state, bool vec, uint
   return __builtin_bswap32(~state);
 }
 
-__device__ __forceinline__ uint32_t slot_fold(const char* nib, const Acc4& a) {
-  return nib_apply(nib + kOpZ16 * kNibOpBytes, a.a0) ^ nib_apply(nib + kOpZ12 * kNibOpBytes, a.a1) ^
-         nib_apply(nib + kOpZ8 * kNibOpBytes, a.a2) ^ nib_apply(nib + kOpZ4 * kNibOpBytes, a.a3);
+__device__ __forceinline__ uint32_t slot_fold(const char* lds, const Acc4& a) {
+  return nib_apply(lds, kOpZ16, a.a0) ^ nib_apply(lds, kOpZ12, a.a1) ^ nib_apply(lds, kOpZ8, a.a2) ^
+         nib_apply(lds, kOpZ4, a.a3);
 }
 
 // Folds the accumulators of a wavefront's two rows.  The result, valid in lane 63, is the register a
 // zero-initialised CRC would hold after the 2 KiB the 512 accumulators spell out.  Row A lies 1 KiB in
 // front of row B, so lane by lane A is advanced by 1 KiB and merged into B before the lanes are folded.
-__device__ __forceinline__ uint32_t wave_fold(const char* nib, const Acc4& a, const Acc4& b, int lane) {
-  const uint32_t x = nib_apply(nib + kOpZ16 * kNibOpBytes, a.a0) ^ nib_apply(nib + kOpZ12 * kNibOpBytes, a.a1) ^
-                     nib_apply(nib + kOpZ8 * kNibOpBytes, a.a2) ^ nib_apply(nib + kOpZ4 * kNibOpBytes, a.a3);
-  uint32_t y = nib_apply(nib + kOpZ16 * kNibOpBytes, b.a0) ^ nib_apply(nib + kOpZ12 * kNibOpBytes, b.a1) ^
-               nib_apply(nib + kOpZ8 * kNibOpBytes, b.a2) ^ nib_apply(nib + kOpZ4 * kNibOpBytes, b.a3);
-  y ^= nib_apply(nib + kOpZ1024 * kNibOpBytes, x);
+__device__ __forceinline__ uint32_t wave_fold(const char* lds, const Acc4& a, const Acc4& b, int lane) {
+  const uint32_t x = slot_fold(lds, a);
+  uint32_t y = slot_fold(lds, b) ^ nib_apply(lds, kOpZ1024, x);
 #pragma unroll
   for (int i = 0; i < 6; i++) {
-    uint32_t t = __shfl_up(y, 1u << i, 64);
-    t = nib_apply(nib + (kOpZ16 + i) * kNibOpBytes, t);
+    const uint32_t t = nib_apply(lds, kOpZ16 + i, lanes_up(y, i));
     y ^= (lane >= (1 << i)) ? t : 0u;
   }
   return y;
@@ -249,7 +290,6 @@ __global__ __launch_bounds__(kThreads) void crc_windows_kernel(const CrcLaunch p
   build_tables(lds, pb, kMainOp, tid);
   __syncthreads();
 
-  const char* nib = lds + kNibOff;
   uint32_t* part = reinterpret_cast<uint32_t*>(lds + kPartOff);
   const uint32_t lb01 = (uint32_t)(lane & 31) * 4u;
   const uint32_t lb23 = lb01 + 65536u;
@@ -266,8 +306,7 @@ __global__ __launch_bounds__(kThreads) void crc_windows_kernel(const CrcLaunch p
     bool vec = false;
     uint32_t r = 0;
     if (valid) {
-      chunk = g / p.wpc;
-      wi = g - chunk * p.wpc;
+      split_window(p, g, chunk, wi);
       const uint64_t woff = wi * (uint64_t)p.bpc;
       const uint64_t left = p.chunk_len - woff;
       const uint64_t len = left < p.bpc ? left : p.bpc;
@@ -326,7 +365,7 @@ __global__ __launch_bounds__(kThreads) void crc_windows_kernel(const CrcLaunch p
         absorb(lds, lb01, lb23, a, da);
         absorb(lds, lb01, lb23, b, db);
       }
-      r = wave_fold(nib, a, b, lane);
+      r = wave_fold(lds, a, b, lane);
     }
 
     // ---- merge the G wavefronts of a window ----
@@ -339,8 +378,7 @@ __global__ __launch_bounds__(kThreads) void crc_windows_kernel(const CrcLaunch p
       uint32_t x = (lane < G) ? slot[sub * G + lane] : 0u;
 #pragma unroll
       for (int i = 0; (1 << i) < G; i++) {
-        uint32_t t = __shfl_up(x, 1u << i, 64);
-        t = nib_apply(nib + (kOpZ2048 + i) * kNibOpBytes, t);
+        const uint32_t t = nib_apply(lds, kOpZ2048 + i, lanes_up(x, i));
         x ^= (lane >= (1 << i)) ? t : 0u;
       }
       state = __shfl(x, G - 1, 64);
@@ -370,8 +408,7 @@ __device__ __forceinline__ Win window_of(const CrcLaunch& p, uint64_t g) {
   Win w{};
   w.valid = g < p.n_windows;
   if (w.valid) {
-    w.chunk = g / p.wpc;
-    w.wi = g - w.chunk * p.wpc;
+    split_window(p, g, w.chunk, w.wi);
     const uint64_t woff = w.wi * (uint64_t)p.bpc;
     const uint64_t left = p.chunk_len - woff;
     const uint64_t len = left < p.bpc ? left : p.bpc;
@@ -384,7 +421,7 @@ __device__ __forceinline__ Win window_of(const CrcLaunch& p, uint64_t g) {
   return w;
 }
 
-template <int LPW, int MODE>
+template <int LPW, int MODE, bool AL>
 __global__ __launch_bounds__(kThreads) void crc_subwave_kernel(const CrcLaunch p) {
   __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
   constexpr uint32_t kStripe = 16u * LPW;
@@ -399,7 +436,6 @@ __global__ __launch_bounds__(kThreads) void crc_subwave_kernel(const CrcLaunch p
   build_tables(lds, c_basis[p.poly_idx], kMainOp, tid);
   __syncthreads();
 
-  const char* nib = lds + kNibOff;
   const uint32_t lb01 = (uint32_t)(lane & 31) * 4u;
   const uint32_t lb23 = lb01 + 65536u;
   const int sl = lane & (LPW - 1);  // lane inside its window's group
@@ -413,13 +449,13 @@ __global__ __launch_bounds__(kThreads) void crc_subwave_kernel(const CrcLaunch p
     uintptr_t ua = wa.e16 - (uintptr_t)wa.nst * kStripe + 16u * sl;
     uintptr_t ub = wb.e16 - (uintptr_t)wb.nst * kStripe + 16u * sl;
     Acc4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
-    if (wa.nst) a = first_unit(ua, wa.s);
-    if (wb.nst) b = first_unit(ub, wb.s);
+    if (wa.nst) a = AL ? first_unit_aligned(ua, wa.s) : first_unit(ua, wa.s);
+    if (wb.nst) b = AL ? first_unit_aligned(ub, wb.s) : first_unit(ub, wb.s);
     ua += kStripe;
     ub += kStripe;
     uint4 na = make_uint4(0, 0, 0, 0), nb = make_uint4(0, 0, 0, 0);
-    if (1 < wa.nst) na = xor4(ld16(ua), init_spill(ua, wa.s));
-    if (1 < wb.nst) nb = xor4(ld16(ub), init_spill(ub, wb.s));
+    if (1 < wa.nst) na = AL ? ld16(ua) : xor4(ld16(ua), init_spill(ua, wa.s));
+    if (1 < wb.nst) nb = AL ? ld16(ub) : xor4(ld16(ub), init_spill(ub, wb.s));
     for (uint32_t j = 1; __ballot(j < wa.nst || j < wb.nst) != 0ull; j++) {
       const uint4 ca = na, cb = nb;
       ua += kStripe;
@@ -429,14 +465,18 @@ __global__ __launch_bounds__(kThreads) void crc_subwave_kernel(const CrcLaunch p
       if (j < wa.nst) absorb(lds, lb01, lb23, a, ca);
       if (j < wb.nst) absorb(lds, lb01, lb23, b, cb);
     }
-    uint32_t x = slot_fold(nib, a), y = slot_fold(nib, b);
+    // Fold.  Only the last lane of a group needs its window's register, so level i has work for the lanes
+    // whose low i+1 bits are all ones (they take in the lane 2^i below).  That leaves the lanes below idle:
+    // they advance row B's values in the same instruction stream, and the result moves up by one DPP shift.
+    // Lanes outside that pattern end up with values nobody reads.
+    uint32_t x = slot_fold(lds, a), y = slot_fold(lds, b);
 #pragma unroll
     for (int i = 0; i < kLevels; i++) {
-      uint32_t tx = __shfl_up(x, 1u << i, 64), ty = __shfl_up(y, 1u << i, 64);
-      tx = nib_apply(nib + (kOpZ16 + i) * kNibOpBytes, tx);
-      ty = nib_apply(nib + (kOpZ16 + i) * kNibOpBytes, ty);
-      x ^= (sl >= (1 << i)) ? tx : 0u;
-      y ^= (sl >= (1 << i)) ? ty : 0u;
+      const bool taker = (sl & ((2 << i) - 1)) == (2 << i) - 1;
+      const uint32_t below = lanes_up(x, i);  // outside the select: every lane must execute the shift
+      const uint32_t t = nib_apply(lds, kOpZ16 + i, taker ? below : y);
+      x ^= t;
+      y ^= lanes_up(t, i);
     }
     if (sl == LPW - 1) {  // the last lane of a group holds its window's register
       if (wa.valid) emit<MODE>(p, ga, wa.chunk, wa.wi, finish_window(x, wa.vec, wa.s, wa.e16, wa.e, poly));
@@ -445,13 +485,13 @@ __global__ __launch_bounds__(kThreads) void crc_subwave_kernel(const CrcLaunch p
   }
 }
 
-template <int MODE>
+template <int MODE, bool AL>
 hipError_t launch_subwave(const CrcLaunch& p, int lpw, int blocks, hipStream_t stream) {
   switch (lpw) {
-    case 4: crc_subwave_kernel<4, MODE><<<blocks, kThreads, 0, stream>>>(p); break;
-    case 8: crc_subwave_kernel<8, MODE><<<blocks, kThreads, 0, stream>>>(p); break;
-    case 16: crc_subwave_kernel<16, MODE><<<blocks, kThreads, 0, stream>>>(p); break;
-    case 32: crc_subwave_kernel<32, MODE><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 4: crc_subwave_kernel<4, MODE, AL><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 8: crc_subwave_kernel<8, MODE, AL><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 16: crc_subwave_kernel<16, MODE, AL><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 32: crc_subwave_kernel<32, MODE, AL><<<blocks, kThreads, 0, stream>>>(p); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -478,6 +518,7 @@ int env_int(const char* name) {
 const int g_force_group = env_int("OZCS_CRC_GROUP");
 const int g_force_pf = env_int("OZCS_CRC_PF");
 const int g_force_lpw = env_int("OZCS_CRC_LPW");  // 4|8|16|32 lanes per window, 64 = never use the small-window kernel
+const int g_no_aligned = env_int("OZCS_CRC_NO_ALIGNED");  // 1 = always take the any-alignment code path
 
 }  // namespace
 
@@ -496,29 +537,36 @@ int crc_choose_group(uint64_t n_windows, uint32_t bpc, int num_cus) {
 }
 
 // Lanes per window for the small-window kernel, or 0 to use the wavefront-per-window kernels.  Measured on
-// MI355X (8 GiB batches): 8 lanes per window is fastest from 512 B to 64 KiB windows (6.3 TB/s at 16 KiB
-// against 5.3 for a wavefront per window; 3.7 against 0.55 at 512 B); 4 lanes read 64-byte pieces and stop
-// at 3.6 TB/s.  Fewer windows ask for more lanes each so that every wavefront still has work; tiny windows
-// cap the lanes so that a window still spans a few stripes.
+// MI355X (16 GiB batches, profiles/): 8 lanes per window is fastest from 256 B to 256 KiB windows (6.7 TB/s
+// at 16 KiB against 5.3 for a wavefront per window; 5.1 against 0.55 at 512 B; 6.96 against 6.75 at 128 KiB);
+// 4 lanes read 64-byte pieces and stop at 3.7 TB/s.  Fewer windows ask for more lanes each so that every
+// wavefront still has work; tiny windows cap the lanes so that a window still spans a few stripes.
 int crc_choose_lpw(uint64_t n_windows, uint32_t bpc, int num_cus) {
   if (g_force_lpw == 4 || g_force_lpw == 8 || g_force_lpw == 16 || g_force_lpw == 32) return g_force_lpw;
   if (g_force_lpw == 64) return 0;
-  if (bpc > 65536) return 0;
+  if (bpc > 262144) return 0;
   const uint64_t waves = (uint64_t)num_cus * kWaves;
   const int want = n_windows >= waves * 16 ? 8 : n_windows >= waves * 8 ? 16 : n_windows >= waves * 4 ? 32 : 64;
-  const int cap = bpc >= 4096 ? 64 : bpc >= 2048 ? 32 : bpc >= 1024 ? 16 : bpc >= 512 ? 8 : 4;
+  const int cap = bpc >= 4096 ? 64 : bpc >= 2048 ? 32 : bpc >= 1024 ? 16 : bpc >= 256 ? 8 : 4;
   const int lpw = want < cap ? want : cap;
   return lpw == 64 ? 0 : lpw;
 }
 
-hipError_t crc_launch(const CrcLaunch& p, int mode, int group, int num_cus, hipStream_t stream) {
-  if (p.n_windows == 0) return hipSuccess;
+hipError_t crc_launch(const CrcLaunch& launch, int mode, int group, int num_cus, hipStream_t stream) {
+  if (launch.n_windows == 0) return hipSuccess;
+  CrcLaunch p = launch;
+  p.wpc_shift = (p.wpc & (p.wpc - 1)) == 0 ? __builtin_ctzll(p.wpc) : -1;
   if (const int lpw = crc_choose_lpw(p.n_windows, p.bpc, num_cus)) {
     const uint64_t per_block = (uint64_t)kWaves * 2 * (64 / lpw);
     uint64_t nb = (p.n_windows + per_block - 1) / per_block;
     if (nb > (uint64_t)num_cus) nb = num_cus;
-    return mode == kModeCompute ? launch_subwave<kModeCompute>(p, lpw, (int)nb, stream)
-                                : launch_subwave<kModeVerify>(p, lpw, (int)nb, stream);
+    // every window starts on a 16-byte boundary: the masking of partial leading units is not needed
+    const bool aligned = !g_no_aligned && ((reinterpret_cast<uintptr_t>(p.data) | p.chunk_stride | p.bpc) & 15u) == 0;
+    if (aligned)
+      return mode == kModeCompute ? launch_subwave<kModeCompute, true>(p, lpw, (int)nb, stream)
+                                  : launch_subwave<kModeVerify, true>(p, lpw, (int)nb, stream);
+    return mode == kModeCompute ? launch_subwave<kModeCompute, false>(p, lpw, (int)nb, stream)
+                                : launch_subwave<kModeVerify, false>(p, lpw, (int)nb, stream);
   }
   const uint64_t per_block = kWaves / group;
   uint64_t blocks = (p.n_windows + per_block - 1) / per_block;

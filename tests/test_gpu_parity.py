@@ -104,6 +104,11 @@ CRC_SHAPES = [
     (7, 1500000, 1500007, 1000),
     (5, 9000001, 9000001, 4099),
     (2, 70 * MIB + 5, 70 * MIB + 16, 16400),
+    # every window 16-byte aligned (the small-window kernel's fast path), ragged last windows
+    (40, 512 * 1024 + 53, 512 * 1024 + 64, 512),
+    (33, MIB + 48, MIB + 48, 1024),
+    (20, 256 * 1024 + 17, 256 * 1024 + 32, 256),
+    (300, 65536 + 3, 65536 + 16, 64),
 ]
 
 

@@ -27,6 +27,10 @@ def main():
         chunk_len = int(rng.integers(1, max_len + 1))
         stride = chunk_len + int(rng.integers(0, 40))
         off = int(rng.integers(0, 16))
+        if case % 3 == 0 and bpc >= 16:   # every window 16-byte aligned: the kernels' fast path
+            bpc = (bpc + 15) // 16 * 16
+            stride = (stride + 15) // 16 * 16
+            off = 0
         t = oracle.CRC32 if case % 2 else oracle.CRC32C
         if digests:
             t = oracle.SHA256 if case % 4 else oracle.MD5
