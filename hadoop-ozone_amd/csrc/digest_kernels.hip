@@ -10,8 +10,9 @@
 // windows with coalesced 16-byte loads (four lanes per window), parks them in LDS in rows of
 // 80 bytes (64 + 16 pad: both the 128-bit stores of the loader role and the 128-bit loads of the
 // owner role are then conflict-free), and every lane runs the compression function on its own
-// block while the loads of the following block are in flight.  Padding blocks are built in
-// registers.  The kernels are integer-ALU bound, not HBM bound.
+// block while the loads of the following block are in flight.  Blocks that are plain data in all
+// 64 windows run in a loop without bounds checks; padding blocks are built in registers.  The
+// kernels are integer-ALU bound, not HBM bound.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -47,6 +48,7 @@ __constant__ const uint32_t kK256[64] = {
 struct Sha256 {
   static constexpr int kWords = 8;
   static constexpr bool kBigEndian = true;
+  static constexpr int kStepBlocks = 1;  // 64-byte blocks fetched per loader step (ALU bound: no need for 2)
   static __device__ __forceinline__ void init(uint32_t* h) {
     h[0] = 0x6a09e667; h[1] = 0xbb67ae85; h[2] = 0x3c6ef372; h[3] = 0xa54ff53a;
     h[4] = 0x510e527f; h[5] = 0x9b05688c; h[6] = 0x1f83d9ab; h[7] = 0x5be0cd19;
@@ -90,6 +92,10 @@ __constant__ const uint32_t kKmd5[64] = {
 struct Md5 {
   static constexpr int kWords = 4;
   static constexpr bool kBigEndian = false;
+  // 64-byte blocks fetched per loader step.  Measured on MI355X: 2 (whole 128-byte lines) gives 4.05 / 4.35 TB/s
+  // at 16 / 64 KiB windows against 3.95 / 4.18 with 1, but 2.45 against 3.04 TB/s at 1 MiB windows (32 GiB),
+  // where one wavefront per SIMD runs a long chain; HBM traffic equals the input size either way.
+  static constexpr int kStepBlocks = 1;
   static __device__ __forceinline__ void init(uint32_t* h) {
     h[0] = 0x67452301; h[1] = 0xefcdab89; h[2] = 0x98badcfe; h[3] = 0x10325476;
   }
@@ -115,32 +121,43 @@ struct Md5 {
 };
 
 constexpr int kLanes = 64;
-constexpr int kRowBytes = 80;  // 64-byte block + 16 bytes of pad per window slot
+// LDS row of one window slot: PB 64-byte blocks + 16 bytes of pad (80 or 144 bytes: the 128-bit stores of
+// the loader role and the 128-bit loads of the owner role are then both conflict-free).
+template <int PB>
+constexpr int row_bytes() { return PB * 64 + 16; }
+constexpr int kRowBytes = row_bytes<1>();
 
-// Loader role of a wavefront: for instruction i a lane fetches 16-byte piece (lane & 3) of the current
-// 64-byte block of window slot 16*i + (lane >> 2), so that one instruction reads 16 windows x 64 B.
+// Loader role of a wavefront.  A step covers PB consecutive 64-byte blocks of each of the 64 windows:
+// 4*PB lanes fetch the 16-byte pieces of one window slot, so one instruction reads 16/PB windows x 64*PB
+// contiguous bytes and 4*PB instructions read the step.  PB = 2 reads whole 128-byte lines; with PB = 1
+// each line is touched by two separate steps and throughput stops at 3.8 TB/s, which only MD5 can exceed.
+template <int PB>
 struct BlockLoader {
-  uint64_t lstart[4];
-  uint32_t llen[4];
+  static constexpr int kInstr = 4 * PB;        // load instructions per step
+  static constexpr int kLanesPerSlot = 4 * PB;
+  static constexpr int kSlotsPerInstr = kLanes / kLanesPerSlot;
+  static constexpr uint32_t kStepBytes = 64u * PB;
+  uint64_t lstart[kInstr];
+  uint32_t llen[kInstr];
   uint32_t piece;
   int lane;
 
   __device__ __forceinline__ void init(int lane_, bool valid, uint64_t start, uint32_t len) {
     lane = lane_;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int slot = 16 * i + (lane >> 2);
+    for (int i = 0; i < kInstr; i++) {
+      const int slot = kSlotsPerInstr * i + lane / kLanesPerSlot;
       const uint32_t lo = __shfl((uint32_t)start, slot, 64), hi = __shfl((uint32_t)(start >> 32), slot, 64);
       lstart[i] = ((uint64_t)hi << 32) | lo;
       llen[i] = __shfl(valid ? len : 0u, slot, 64);
     }
-    piece = (lane & 3) * 16;
+    piece = (lane % kLanesPerSlot) * 16;
   }
 
-  __device__ __forceinline__ void fetch(uint32_t blk, u32x4* r) const {
+  __device__ __forceinline__ void fetch(uint32_t step, u32x4* r) const {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const uint64_t o = (uint64_t)blk * 64 + piece;
+    for (int i = 0; i < kInstr; i++) {
+      const uint64_t o = (uint64_t)step * kStepBytes + piece;
       u32x4 v = {0, 0, 0, 0};
       if (o + 16 <= llen[i]) {
         v = *reinterpret_cast<gptr_u4u>(lstart[i] + o);
@@ -156,28 +173,42 @@ struct BlockLoader {
     }
   }
 
-  // Parks the fetched pieces in the 80-byte rows of `stage` (row = window slot).
+  // fetch() for a step that lies wholly inside every one of the wavefront's 64 windows: no bounds to check.
+  // Plain (cached) loads: with PB = 1 a 128-byte line serves two consecutive steps, and non-temporal loads
+  // made the second one fetch it from HBM again.
+  __device__ __forceinline__ void fetch_inside(uint32_t step, u32x4* r) const {
+    const uint64_t o = (uint64_t)step * kStepBytes + piece;
+#pragma unroll
+    for (int i = 0; i < kInstr; i++) r[i] = *reinterpret_cast<gptr_u4u>(lstart[i] + o);
+  }
+
+  // Parks the fetched pieces in the rows of `stage` (row = window slot).
   __device__ __forceinline__ void park(char* stage, const u32x4* r) const {
 #pragma unroll
-    for (int i = 0; i < 4; i++)
-      *reinterpret_cast<u32x4*>(stage + (16 * i + (lane >> 2)) * kRowBytes + piece) = r[i];
+    for (int i = 0; i < kInstr; i++)
+      *reinterpret_cast<u32x4*>(stage + (kSlotsPerInstr * i + lane / kLanesPerSlot) * row_bytes<PB>() + piece) = r[i];
   }
 };
 
-// Owner role: reads this lane's own 64-byte block from `stage` as 16 words in the hash's word order and
-// builds the padding (0x80, zeros, bit length) where the message ends.
+// Owner role: reads a 64-byte block at `row` (this lane's row of `stage`, plus the block's offset in the
+// step) as 16 words in the hash's word order.
 template <class H>
-__device__ __forceinline__ void block_words(const char* stage, int lane, uint32_t blk, uint32_t len, uint32_t nblk,
-                                            uint32_t* w) {
+__device__ __forceinline__ void data_words(const char* row, uint32_t* w) {
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    const u32x4 v = *reinterpret_cast<const u32x4*>(stage + lane * kRowBytes + 16 * j);
+    const u32x4 v = *reinterpret_cast<const u32x4*>(row + 16 * j);
     w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
   }
   if (H::kBigEndian) {
 #pragma unroll
     for (int j = 0; j < 16; j++) w[j] = __builtin_bswap32(w[j]);
   }
+}
+
+// data_words plus the padding (0x80, zeros, bit length) where the message ends.
+template <class H>
+__device__ __forceinline__ void block_words(const char* row, uint32_t blk, uint32_t len, uint32_t nblk, uint32_t* w) {
+  data_words<H>(row, w);
   const int64_t rem = (int64_t)len - (int64_t)blk * 64;  // message bytes from this block on
   if (rem < 64) {  // this block holds the end of the message and/or padding
 #pragma unroll
@@ -202,23 +233,53 @@ __device__ __forceinline__ uint32_t num_blocks(bool valid, uint32_t len) {
 }
 
 // Hashes this lane's window [start, start+len) (nothing when !valid); h receives the digest words in
-// output byte order.  Must be called by all 64 lanes of the one-wavefront workgroup together.
+// output byte order.  Must be called by all 64 lanes of the one-wavefront workgroup together.  `stage` holds
+// 64 rows of row_bytes<H::kStepBlocks>().
 template <class H>
 __device__ __forceinline__ void digest_core(char* stage, int lane, bool valid, uint64_t start, uint32_t len, uint32_t* h) {
+  constexpr int PB = H::kStepBlocks;
   const uint32_t nblk = num_blocks(valid, len);
-  BlockLoader ld;
+  BlockLoader<PB> ld;
   ld.init(lane, valid, start, len);
   H::init(h);
-  u32x4 r[4];
-  ld.fetch(0, r);
-  for (uint32_t blk = 0; __ballot(blk < nblk) != 0ull; blk++) {
-    __syncthreads();  // the previous block has been read by every owner
+  // Steps that are plain data in every window of the wavefront (none if a lane has no window) run in a
+  // loop of their own without bounds checks or padding logic: that bookkeeping is a third of the
+  // instructions of an MD5 block.
+  uint32_t inside = valid ? len / (64u * PB) : 0u;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t other = __shfl_xor(inside, o, 64);
+    inside = other < inside ? other : inside;
+  }
+  const char* row = stage + lane * row_bytes<PB>();
+  u32x4 r[BlockLoader<PB>::kInstr];
+  uint32_t step = 0;
+  if (inside > 0) ld.fetch_inside(0, r);
+  else ld.fetch(0, r);
+  for (; step + 1 < inside; step++) {  // steps `step` and `step + 1` are inside everywhere
+    __syncthreads();  // the previous step has been read by every owner
     ld.park(stage, r);
     __syncthreads();
-    ld.fetch(blk + 1, r);  // in flight during the compression below
-    uint32_t w[16];
-    block_words<H>(stage, lane, blk, len, nblk, w);
-    if (blk < nblk) H::compress(h, w);
+    ld.fetch_inside(step + 1, r);  // in flight during the compression below
+#pragma unroll
+    for (int k = 0; k < PB; k++) {
+      uint32_t w[16];
+      data_words<H>(row + 64 * k, w);
+      H::compress(h, w);
+    }
+  }
+  for (; __ballot(step * PB < nblk) != 0ull; step++) {
+    __syncthreads();
+    ld.park(stage, r);
+    __syncthreads();
+    ld.fetch(step + 1, r);
+#pragma unroll
+    for (int k = 0; k < PB; k++) {
+      const uint32_t blk = step * PB + k;
+      uint32_t w[16];
+      block_words<H>(row + 64 * k, blk, len, nblk, w);
+      if (blk < nblk) H::compress(h, w);
+    }
   }
   if (H::kBigEndian) {
 #pragma unroll
@@ -260,7 +321,7 @@ __device__ __forceinline__ void sha256_split_core(char* stage_all, char* wbuf_al
   if (lane == 0) sync[wave] = nmax;  // every wavefront must pass the same number of barriers
   __syncthreads();
   nmax = sync[0] > sync[1] ? sync[0] : sync[1];
-  BlockLoader ld;
+  BlockLoader<1> ld;
   u32x4 r[4];
   if (!compressor) {
     ld.init(lane, valid, start, len);
@@ -276,7 +337,7 @@ __device__ __forceinline__ void sha256_split_core(char* stage_all, char* wbuf_al
         __builtin_amdgcn_wave_barrier();                        // operations execute in issue order
         ld.fetch(blk + 1, r);
         uint32_t w[16];
-        block_words<Sha256>(stage, lane, blk, len, nblk, w);
+        block_words<Sha256>(stage + lane * kRowBytes, blk, len, nblk, w);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
         char* dst = wbuf + (blk & 1) * kWBufBytes + lane * 16;
@@ -335,7 +396,7 @@ __device__ __forceinline__ void store_digest(uint8_t* out, const uint32_t* h) {
 // Uniform batch: chunk c at data + c*chunk_stride, wpc windows per chunk.
 template <class H, int MODE>
 __global__ __launch_bounds__(kLanes) void digest_windows_kernel(const DigestLaunch p) {
-  __shared__ __attribute__((aligned(16))) char stage[kLanes * kRowBytes];
+  __shared__ __attribute__((aligned(16))) char stage[kLanes * row_bytes<H::kStepBlocks>()];
   const int lane = threadIdx.x;
   const uint64_t g = (uint64_t)blockIdx.x * kLanes + lane;
   const bool valid = g < p.n_windows;
@@ -371,7 +432,7 @@ __global__ __launch_bounds__(kLanes) void digest_windows_kernel(const DigestLaun
 // so that a handful of windows per chunk still adds up to full wavefronts.
 template <class H>
 __global__ __launch_bounds__(kLanes) void digest_jobs_kernel(const DigestJobList p) {
-  __shared__ __attribute__((aligned(16))) char stage[kLanes * kRowBytes];
+  __shared__ __attribute__((aligned(16))) char stage[kLanes * row_bytes<H::kStepBlocks>()];
   const int lane = threadIdx.x;
   const uint32_t g = blockIdx.x * kLanes + lane;
   const bool valid = g < p.n_windows;

@@ -146,6 +146,8 @@ int maybe_flush(ozcs_pipe* p, size_t limit) {
 
 extern "C" {
 
+uint64_t ozcs_pipe_slot_bytes(const ozcs_pipe* pipe) { return pipe ? pipe->slot_bytes : 0; }
+
 int ozcs_pipe_create(int device, uint32_t n_slots, uint64_t slot_bytes, ozcs_pipe** out) {
   if (!out) return fail(OZCS_EINVAL, "null out");
   *out = nullptr;

@@ -92,8 +92,7 @@ JNIEXPORT jobject JNICALL JFN(pipeAcquire)(JNIEnv* env, jclass cls, jlong pipe, 
   if (ozcs_pipe_acquire((ozcs_pipe*)(intptr_t)pipe, &buf, &ticket) != OZCS_OK) return NULL;
   const jint t = ticket;
   (*env)->SetIntArrayRegion(env, ticketOut, 0, 1, &t);
-  /* the slot size is the pipe's; Java knows it from pipeCreate and slices the buffer accordingly */
-  return (*env)->NewDirectByteBuffer(env, buf, (jlong)1 << 30);
+  return (*env)->NewDirectByteBuffer(env, buf, (jlong)ozcs_pipe_slot_bytes((ozcs_pipe*)(intptr_t)pipe));
 }
 
 JNIEXPORT jint JNICALL JFN(pipeSubmit)(JNIEnv* env, jclass cls, jlong pipe, jint ticket, jint type, jint bpc,

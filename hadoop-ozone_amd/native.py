@@ -60,6 +60,7 @@ SIGNATURES = {
     "ozcs_get_stats": (None, [ctypes.POINTER(OzcsStats)]),
     "ozcs_pipe_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p)]),
     "ozcs_pipe_destroy": (None, [ctypes.c_void_p]),
+    "ozcs_pipe_slot_bytes": (ctypes.c_uint64, [ctypes.c_void_p]),
     "ozcs_pipe_acquire": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int)]),
     "ozcs_pipe_submit_slot": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint32,
                                              ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64]),

@@ -68,6 +68,8 @@ enum ozcs_status {
 /* Initialises the library on the devices selected by device_mask (bit i = HIP device i; 0 = all).
  * Idempotent and thread-safe.  Returns OZCS_ENODEV when no device is usable. */
 OZCS_API int ozcs_init(uint32_t device_mask);
+/* Releases streams and device buffers.  Not to be called while another thread is inside a library call or
+ * while a pipe exists; ozcs_init may be called again afterwards. */
 OZCS_API void ozcs_shutdown(void);
 /* 1 when ozcs_init has succeeded (calling it first if needed), else 0. */
 OZCS_API int ozcs_available(void);
@@ -168,6 +170,9 @@ typedef struct ozcs_pipe ozcs_pipe;
 
 OZCS_API int ozcs_pipe_create(int device, uint32_t n_slots, uint64_t slot_bytes, ozcs_pipe** out);
 OZCS_API void ozcs_pipe_destroy(ozcs_pipe* pipe);
+/* Capacity of every slot buffer of the pipe in bytes (the slot_bytes it was created with); 0 for NULL.
+ * A binding that wraps a slot in a bounded buffer object (a direct ByteBuffer) sizes it with this. */
+OZCS_API uint64_t ozcs_pipe_slot_bytes(const ozcs_pipe* pipe);
 
 /* Borrow a free slot: *buf is its pinned host buffer of slot_bytes bytes for the producer to fill in place
  * (zero staging copies).  OZCS_EBUSY when every slot is in flight. */

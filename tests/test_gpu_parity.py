@@ -541,3 +541,25 @@ def test_bench_two_ranks_rehearsal(gpu):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0 and "cpu_baseline" not in rec
     assert rec["config"]["blocks_per_gpu"] == 2
+
+
+def test_stats_counters_and_pipe_slot_bytes(gpu):
+    torch, native, L = gpu
+    before = native.stats()
+    data = oracle.splitmix64(77, 3 * MIB + 5)
+    sums = native.compute(oracle.CRC32C, MIB, data)
+    assert sums == oracle.compute(oracle.CRC32C, MIB, data)
+    after = native.stats()
+    assert after["calls"] == before["calls"] + 1
+    assert after["bytes_hashed"] == before["bytes_hashed"] + data.size
+    assert after["windows"] == before["windows"] + 4
+    assert after["h2d_bytes"] == before["h2d_bytes"] + data.size
+    assert after["d2h_bytes"] == before["d2h_bytes"] + 16
+    assert after["kernel_launches"] == before["kernel_launches"] + 1
+    pipe = ctypes.c_void_p()
+    native.check(L.ozcs_pipe_create(0, 2, 123456, ctypes.byref(pipe)))
+    try:
+        assert L.ozcs_pipe_slot_bytes(pipe) == 123456
+    finally:
+        L.ozcs_pipe_destroy(pipe)
+    assert L.ozcs_pipe_slot_bytes(None) == 0
