@@ -33,6 +33,10 @@ __device__ __forceinline__ uint32_t rotr(uint32_t x, int n) { return __builtin_a
 __device__ __forceinline__ uint32_t rotl(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, 32 - n); }
 // Three-input bitwise functions in one instruction (v_bitop3_b32; the table is the function of 0xF0, 0xCC, 0xAA).
 __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+// Ch(e,f,g) = (e & f) ^ (~e & g) and Maj(a,b,c): written as source expressions they compile to a
+// v_bitop3 plus an and and an xor each round; spelled out they are one instruction each.
+__device__ __forceinline__ uint32_t choose(uint32_t e, uint32_t f, uint32_t g) { return __builtin_amdgcn_bitop3_b32(e, f, g, 0xCA); }
+__device__ __forceinline__ uint32_t majority(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8); }
 
 // ------------------------------------------------------------------ SHA-256 (FIPS 180-4, 6.2.2)
 __constant__ const uint32_t kK256[64] = {
@@ -67,10 +71,10 @@ struct Sha256 {
         wi = w[i & 15] = w[i & 15] + s0 + w[(i + 9) & 15] + s1;
       }
       const uint32_t S1 = xor3(rotr(e, 6), rotr(e, 11), rotr(e, 25));
-      const uint32_t ch = (e & f) ^ (~e & g);
+      const uint32_t ch = choose(e, f, g);
       const uint32_t t1 = hh + S1 + ch + kK256[i] + wi;
       const uint32_t S0 = xor3(rotr(a, 2), rotr(a, 13), rotr(a, 22));
-      const uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
+      const uint32_t mj = majority(a, b, c);
       const uint32_t t2 = S0 + mj;
       hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
     }
@@ -359,20 +363,30 @@ __device__ __forceinline__ void sha256_split_core(char* stage_all, char* wbuf_al
     } else if (blk >= 1 && blk - 1 < nblk) {
       const char* src = wbuf + ((blk - 1) & 1) * kWBufBytes + lane * 16;
       uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+      // W is read eight rounds ahead of its use: the loads of rounds 8(p+1)..8(p+1)+7 are issued before
+      // the rounds 8p..8p+7 run (the scheduling barrier keeps them there), so the LDS latency is covered.
+      u32x4 v0 = *reinterpret_cast<const u32x4*>(src), v1 = *reinterpret_cast<const u32x4*>(src + kLanes * 16);
 #pragma unroll
-      for (int q = 0; q < 16; q++) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(src + q * (kLanes * 16));
-        const uint32_t wq[4] = {v.x, v.y, v.z, v.w};
+      for (int p = 0; p < 8; p++) {
+        u32x4 n0 = v0, n1 = v1;
+        if (p < 7) {
+          n0 = *reinterpret_cast<const u32x4*>(src + (2 * p + 2) * (kLanes * 16));
+          n1 = *reinterpret_cast<const u32x4*>(src + (2 * p + 3) * (kLanes * 16));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t wq[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < 8; k++) {
           const uint32_t S1 = xor3(rotr(e, 6), rotr(e, 11), rotr(e, 25));
-          const uint32_t ch = (e & f) ^ (~e & g);
-          const uint32_t t1 = hh + S1 + ch + kK256[4 * q + k] + wq[k];
+          const uint32_t ch = choose(e, f, g);
+          const uint32_t t1 = hh + S1 + ch + kK256[8 * p + k] + wq[k];
           const uint32_t S0 = xor3(rotr(a, 2), rotr(a, 13), rotr(a, 22));
-          const uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
+          const uint32_t mj = majority(a, b, c);
           const uint32_t t2 = S0 + mj;
           hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
         }
+        v0 = n0;
+        v1 = n1;
       }
       h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
     }
