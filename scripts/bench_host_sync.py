@@ -35,3 +35,24 @@ for _ in range(8):
     native.check(L.ozcs_compute_batch(arr, n))
 dt = time.perf_counter() - t0
 print(json.dumps({"call": "ozcs_compute_batch 64 x 4 MiB", "GBps": round(8 * n * 4 * MIB / dt / 1e9, 2)}), flush=True)
+# many caller threads, one 4 MiB heap chunk each per call (the shape of many open BlockOutputStreams)
+import threading
+for nthreads in (1, 2, 4, 8, 16):
+    datas = [rng.integers(0, 256, 4 * MIB, dtype=np.uint8) for _ in range(nthreads)]
+    reps = 128
+    lib = native.lib()
+
+    def work(d):
+        out = ctypes.create_string_buffer(16)
+        n = ctypes.c_uint64()
+        for _ in range(reps):
+            lib.ozcs_compute(native.CRC32, MIB, d.ctypes.data, d.size, out, 16, ctypes.byref(n))
+    ts = [threading.Thread(target=work, args=(d,)) for d in datas]
+    t0 = time.perf_counter()
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    dt = time.perf_counter() - t0
+    print(json.dumps({"call": "ozcs_compute 4 MiB from %d threads" % nthreads,
+                      "GBps": round(nthreads * reps * 4 * MIB / dt / 1e9, 2)}), flush=True)
