@@ -67,6 +67,14 @@ void free_slot(Slot& s) {
   s = Slot();
 }
 
+// hipEventQuery that does not leave hipErrorNotReady behind as the thread's last error (the caller's own
+// HIP code would otherwise find it there).
+hipError_t query_event(hipEvent_t ev) {
+  const hipError_t e = hipEventQuery(ev);
+  if (e == hipErrorNotReady) (void)hipGetLastError();
+  return e;
+}
+
 // Completes a slot whose `done` event has fired: hands the digests over and frees the slot.
 void retire(Slot& s) {
   if (s.status == OZCS_OK && s.sums_len) memcpy(s.user_sums, s.h_sums, s.sums_len);
@@ -137,7 +145,7 @@ int flush_deferred(ozcs_pipe* p) {
 // while the next gathers) or when `limit` slots have gathered.  Caller holds p->mu.
 int maybe_flush(ozcs_pipe* p, size_t limit) {
   if (p->deferred.empty()) return OZCS_OK;
-  if (p->digest_running && hipEventQuery(p->digest_done) == hipSuccess) p->digest_running = false;
+  if (p->digest_running && query_event(p->digest_done) == hipSuccess) p->digest_running = false;
   if (!p->digest_running || p->deferred.size() >= limit) return flush_deferred(p);
   return OZCS_OK;
 }
@@ -212,19 +220,19 @@ int ozcs_pipe_acquire(ozcs_pipe* p, void** buf, int* ticket) {
   if (!p || !buf || !ticket) return fail(OZCS_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(p->mu);
   DeviceGuard dg(p->device);
-  for (int pass = 0; pass < 2; pass++) {
-    if (pass == 1) (void)maybe_flush(p, p->slots.size() / 2 ? p->slots.size() / 2 : 1);  // parked digest slots finish only once launched
-    for (size_t i = 0; i < p->slots.size(); i++) {
-      Slot& s = p->slots[i];
-      if (pass == 1 && s.state == kInFlight && !s.deferred && hipEventQuery(s.done) == hipSuccess) retire(s);  // reap
-      if (s.state == kFree) {
-        s.state = kAcquired;
-        *buf = s.h_data;
-        *ticket = (int)i;
-        return OZCS_OK;
-      }
+  // A slot stays its ticket holder's until that ticket has been polled to completion, waited for or
+  // drained: a finished slot is never recycled behind its owner's back.
+  for (size_t i = 0; i < p->slots.size(); i++) {
+    Slot& s = p->slots[i];
+    if (s.state == kFree) {
+      s.state = kAcquired;
+      *buf = s.h_data;
+      *ticket = (int)i;
+      return OZCS_OK;
     }
   }
+  // parked digest slots finish only once launched
+  (void)maybe_flush(p, p->slots.size() / 2 ? p->slots.size() / 2 : 1);
   return fail(OZCS_EBUSY, "all %zu slots are in flight", p->slots.size());
 }
 
@@ -312,7 +320,19 @@ static int finish(ozcs_pipe* p, int ticket, uint64_t* n_sums, bool block) {
   if (s.state == kInFlight) {
     DeviceGuard dg(p->device);
     if (s.deferred) (void)flush_deferred(p);
-    hipError_t e = block ? hipEventSynchronize(s.done) : hipEventQuery(s.done);
+    hipError_t e = query_event(s.done);
+    if (e == hipErrorNotReady && block) {
+      // wait without the pipe's lock, so that other threads keep submitting meanwhile; only the ticket's
+      // holder or ozcs_pipe_drain can complete this slot, and drain leaves the same result behind
+      hipEvent_t done = s.done;
+      lk.unlock();
+      e = hipEventSynchronize(done);
+      lk.lock();
+      if (s.state != kInFlight) {  // drained by another thread while this one waited
+        if (n_sums) *n_sums = s.n_sums;
+        return s.status;
+      }
+    }
     if (e == hipErrorNotReady) return OZCS_EBUSY;
     if (e != hipSuccess) {
       s.status = OZCS_EHIP;

@@ -175,7 +175,8 @@ OZCS_API void ozcs_pipe_destroy(ozcs_pipe* pipe);
 OZCS_API uint64_t ozcs_pipe_slot_bytes(const ozcs_pipe* pipe);
 
 /* Borrow a free slot: *buf is its pinned host buffer of slot_bytes bytes for the producer to fill in place
- * (zero staging copies).  OZCS_EBUSY when every slot is in flight. */
+ * (zero staging copies).  OZCS_EBUSY when no slot is free: a submitted slot stays its ticket's until that
+ * ticket has been polled to completion, waited for or drained. */
 OZCS_API int ozcs_pipe_acquire(ozcs_pipe* pipe, void** buf, int* ticket);
 /* Queue copy + checksum + copy-back for the first `len` bytes of an acquired slot.  sums_out (host, any
  * memory) receives the digests when the ticket completes. */

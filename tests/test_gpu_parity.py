@@ -6,6 +6,7 @@ oracle, GF(2) linearity of CRC, invariance under chunk permutation, verify-after
 """
 import ctypes
 import threading
+import time
 
 import numpy as np
 import pytest
@@ -563,3 +564,45 @@ def test_stats_counters_and_pipe_slot_bytes(gpu):
     finally:
         L.ozcs_pipe_destroy(pipe)
     assert L.ozcs_pipe_slot_bytes(None) == 0
+
+
+def test_pipe_shared_by_threads(gpu):
+    # one pipe, four producer threads (one per open BlockOutputStream): every ticket is waited by its holder
+    import threading
+    torch, native, L = gpu
+    pipe = ctypes.c_void_p()
+    native.check(L.ozcs_pipe_create(0, 6, MIB, ctypes.byref(pipe)))
+    errors = []
+
+    def producer(k):
+        try:
+            for i in range(12):
+                t = oracle.CRC32C if (i + k) % 3 else oracle.MD5
+                ln = MIB - 37 * i - k
+                bpc = 65536 if i % 2 else 16384
+                d = oracle.splitmix64(5000 + 100 * k + i, ln)
+                ds = native.DIGEST_SIZE[t]
+                out = ctypes.create_string_buffer(((ln + bpc - 1) // bpc) * ds)
+                ticket = ctypes.c_int(-1)
+                while True:
+                    rc = L.ozcs_pipe_submit(pipe, t, bpc, d.ctypes.data, ln, out, len(out), ctypes.byref(ticket))
+                    if rc != native.EBUSY:
+                        break
+                    time.sleep(0.0005)   # the other threads hold every slot: theirs to wait for, not ours
+                native.check(rc)
+                n = ctypes.c_uint64()
+                native.check(L.ozcs_pipe_wait(pipe, ticket.value, ctypes.byref(n)))
+                assert n.value == (ln + bpc - 1) // bpc
+                assert out.raw == oracle.compute(t, bpc, d), (k, i)
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    try:
+        ts = [threading.Thread(target=producer, args=(k,)) for k in range(4)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not errors, errors
+    finally:
+        L.ozcs_pipe_destroy(pipe)
