@@ -46,6 +46,39 @@ __global__ __launch_bounds__(1024) void read_wave_windows(const uint8_t* p, uint
   if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = 1;
 }
 
+// wave-windows with the cache policy spelled in the instruction (POLICY: 0 plain, 1 nt, 2 sc1 nt, 3 sc0 sc1 nt, 4 sc1)
+// and an optional staggered start: wave g begins its window at offset (g * 8 KiB) mod win and wraps, so that the
+// 4096 wavefronts do not all sit at the same offset of their windows.
+template <int POLICY>
+__device__ __forceinline__ u32x4 ld_policy(const uint8_t* a) {
+  u32x4 v;
+  if (POLICY == 0) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(a) : "memory");
+  if (POLICY == 1) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(v) : "v"(a) : "memory");
+  if (POLICY == 2) asm volatile("global_load_dwordx4 %0, %1, off sc1 nt" : "=v"(v) : "v"(a) : "memory");
+  if (POLICY == 3) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1 nt" : "=v"(v) : "v"(a) : "memory");
+  if (POLICY == 4) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(a) : "memory");
+  return v;
+}
+template <int UNROLL, int POLICY, bool STAGGER>
+__global__ __launch_bounds__(1024) void read_wave_windows_policy(const uint8_t* p, uint64_t nwin, uint64_t win, uint32_t* out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  u32x4 acc = {0, 0, 0, 0};
+  for (uint64_t g = (uint64_t)blockIdx.x * 16 + wave; g < nwin; g += (uint64_t)gridDim.x * 16) {
+    const uint8_t* q = p + g * win + 16 * lane;
+    const uint64_t start = STAGGER ? (g * 8192) & (win - 1) : 0;
+    for (uint64_t o = 0; o < win; o += 1024 * UNROLL) {
+      const uint64_t oo = (o + start) & (win - 1);
+      u32x4 v[UNROLL];
+#pragma unroll
+      for (int k = 0; k < UNROLL; k++) v[k] = ld_policy<POLICY>(q + oo + 1024 * k);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < UNROLL; k++) acc ^= v[k];
+    }
+  }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = 1;
+}
+
 // 1024-thread blocks, whole block streams one window in 16 KiB stripes
 template <int UNROLL, bool NT>
 __global__ __launch_bounds__(1024) void read_block_windows(const uint8_t* p, uint64_t nwin, uint64_t win, uint32_t* out) {
@@ -107,6 +140,14 @@ int main(int argc, char** argv) {
   timeit("block-windows 256x1024 unroll8", bytes, [&] { read_block_windows<8, false><<<256, 1024>>>(d, nwin, win, out); });
   timeit("block-windows 256x1024 unroll8 nt", bytes, [&] { read_block_windows<8, true><<<256, 1024>>>(d, nwin, win, out); });
   timeit("block-windows 512x1024 unroll8", bytes, [&] { read_block_windows<8, false><<<512, 1024>>>(d, nwin, win, out); });
+  timeit("wave-windows asm plain", bytes, [&] { read_wave_windows_policy<8, 0, false><<<256, 1024>>>(d, nwin, win, out); });
+  timeit("wave-windows asm nt", bytes, [&] { read_wave_windows_policy<8, 1, false><<<256, 1024>>>(d, nwin, win, out); });
+  timeit("wave-windows asm sc1 nt", bytes, [&] { read_wave_windows_policy<8, 2, false><<<256, 1024>>>(d, nwin, win, out); });
+  timeit("wave-windows asm sc0 sc1 nt", bytes, [&] { read_wave_windows_policy<8, 3, false><<<256, 1024>>>(d, nwin, win, out); });
+  timeit("wave-windows asm sc1", bytes, [&] { read_wave_windows_policy<8, 4, false><<<256, 1024>>>(d, nwin, win, out); });
+  timeit("wave-windows asm nt staggered", bytes, [&] { read_wave_windows_policy<8, 1, true><<<256, 1024>>>(d, nwin, win, out); });
+  timeit("wave-windows asm nt unroll4", bytes, [&] { read_wave_windows_policy<4, 1, false><<<256, 1024>>>(d, nwin, win, out); });
+  timeit("wave-windows asm nt unroll2", bytes, [&] { read_wave_windows_policy<2, 1, false><<<256, 1024>>>(d, nwin, win, out); });
   timeit("hipMemsetAsync (write only)", bytes, [&] { (void)hipMemsetAsync(d, 1, bytes, 0); });
   return 0;
 }
