@@ -1,0 +1,185 @@
+// The three callers of the checksum path, restructured around batched GPU calls, in C++ over
+// ozone_checksum.hpp.  Observable behaviour (what is read, what is raised, with which text) follows the
+// reference; only the per-window CPU loop inside is replaced.
+//
+//   read path   ChunkInputStream.computeChecksumBoundaries / validator
+//               hadoop-hdds/client/src/main/java/org/apache/hadoop/hdds/scm/storage/ChunkInputStream.java:455-535
+//   scrubber    KeyValueContainerCheck.verifyChecksum
+//               hadoop-hdds/container-service/src/main/java/org/apache/hadoop/ozone/container/keyvalue/KeyValueContainerCheck.java:262-322
+//   write path  BlockOutputStream.writeChunkToContainer over BufferPool buffers
+//               hadoop-hdds/client/src/main/java/org/apache/hadoop/hdds/scm/storage/BlockOutputStream.java:495-507, 645-690
+//               hadoop-hdds/client/src/main/java/org/apache/hadoop/hdds/scm/storage/BufferPool.java:74-85
+// Header-only; link libozcs.so.
+#pragma once
+#include <algorithm>
+#include <cstdio>
+#include <functional>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "ozone_checksum.hpp"
+
+namespace ozone {
+
+// ---------------------------------------------------------------------------------------------- read path
+
+// ChunkInputStream.java:522-535: the byte range to fetch so that whole windows can be verified.
+// Returns (adjustedChunkOffset, adjustedChunkLen).
+inline std::pair<long long, long long> computeChecksumBoundaries(long long startByteIndex, int dataLen,
+                                                                 int bytesPerChecksum, long long chunkLength) {
+  const long long endByteIndex = startByteIndex + dataLen - 1;  // inclusive
+  const long long adjustedChunkOffset = (startByteIndex / bytesPerChecksum) * bytesPerChecksum;
+  const long long endIndex = ((endByteIndex / bytesPerChecksum) + 1) * bytesPerChecksum;  // exclusive
+  return {adjustedChunkOffset, std::min(endIndex, chunkLength) - adjustedChunkOffset};
+}
+
+// The ReadChunk response validator (ChunkInputStream.java:455-504).  chunkOffset / checksumData describe the
+// whole chunk, reqOffset / reqLen the (boundary-widened) range that was requested; byteStrings is the
+// response: one element for the V0 layout (isV0), one element per window otherwise.  All windows of the
+// response are verified by one library call (V0) or one batched call (V1) instead of a CPU pass per window
+// with its copy (ChecksumByteBufferImpl.java:42-46).
+inline void validateReadChunk(const std::string& chunkName, long long chunkOffset, const ChecksumData& checksumData,
+                              long long reqOffset, long long reqLen, const std::vector<ByteString>& byteStrings,
+                              bool isV0, bool verifyChecksum = true) {
+  long long got = 0;
+  for (const ByteString& b : byteStrings) got += (long long)b.size();  // BufferUtils.getBuffersLen
+  if (got != reqLen)
+    throw OzoneChecksumException("Inconsistent read for chunk=" + chunkName + " len=" + std::to_string(reqLen) +
+                                 " bytesRead=" + std::to_string(got));
+  if (!verifyChecksum) return;
+  const long long relativeOffset = reqOffset - chunkOffset;
+  const int startIndex = (int)(relativeOffset / checksumData.getBytesPerChecksum());
+  Checksum::verifyChecksum(byteStrings, checksumData, startIndex, isV0);
+}
+
+// ---------------------------------------------------------------------------------------------- scrubber
+
+enum class ChunkLayOutVersion { FILE_PER_CHUNK = 1, FILE_PER_BLOCK = 2 };
+
+// Arrays.toString(byte[]): signed decimal bytes.
+inline std::string javaBytesToString(const ByteString& b) {
+  std::string s = "[";
+  for (size_t i = 0; i < b.size(); i++) {
+    if (i) s += ", ";
+    s += std::to_string((int)(signed char)b[i]);
+  }
+  return s + "]";
+}
+
+// ChunkInfo.toString() (hadoop-hdds/common/src/main/java/org/apache/hadoop/ozone/container/common/helpers/ChunkInfo.java:182-188).
+inline std::string chunkInfoToString(const std::string& chunkName, long long offset, long long len) {
+  return "ChunkInfo{chunkName='" + chunkName + ", offset=" + std::to_string(offset) + ", len=" + std::to_string(len) + "}";
+}
+
+// One chunk of a closed container against its stored ChecksumData (KeyValueContainerCheck.java:262-322).
+// The reference reads, throttles and checks one window at a time; here the chunk's windows are read in one
+// go and checked by one ozcs_verify call.  Kept: FILE_PER_BLOCK positions the file at the chunk's offset and
+// never reads past the chunk (:276-285); the throttler sees every window's byte count in order (:294); the
+// first failing window raises the reference's text (:299-311); a file that ends early at a window boundary
+// raises the length form (:314-320), one that ends inside a window fails that window first.
+// throttler may be empty.  Returns the number of bytes read.
+inline long long verifyChunkFile(const std::string& blockId, const std::string& chunkName, long long chunkOffset,
+                                 long long chunkLen, const ChecksumData& checksumData, const std::string& chunkFile,
+                                 ChunkLayOutVersion layout, const std::function<void(long long)>& throttler = {}) {
+  const std::vector<ByteString>& sums = checksumData.getChecksums();
+  const long long count = (long long)sums.size();
+  const long long bpc = checksumData.getBytesPerChecksum();
+  long long want = count * bpc;
+  if (layout == ChunkLayOutVersion::FILE_PER_BLOCK && count && chunkLen % bpc != 0) want = (count - 1) * bpc + chunkLen % bpc;
+  std::string data((size_t)want, '\0');
+  long long nRead = 0;
+  {
+    FILE* f = std::fopen(chunkFile.c_str(), "rb");
+    if (!f) throw std::runtime_error("cannot open " + chunkFile);
+    if (layout == ChunkLayOutVersion::FILE_PER_BLOCK) std::fseek(f, (long)chunkOffset, SEEK_SET);
+    if (want) nRead = (long long)std::fread(&data[0], 1, (size_t)want, f);
+    std::fclose(f);
+  }
+  const long long windowsRead = bpc ? (nRead + bpc - 1) / bpc : 0;
+  if (throttler)
+    for (long long i = 0; i < windowsRead; i++) throttler(std::min(bpc, nRead - i * bpc));
+  const ChecksumType type = checksumData.getChecksumType();
+  if (type != ChecksumType::NONE && windowsRead) {
+    std::string stored;
+    for (long long i = 0; i < windowsRead; i++) stored += sums[(size_t)i];
+    const int t = (int)type;
+    int64_t first = -1;
+    const int rc = ozcs_verify(t, (uint32_t)bpc, data.data(), (uint64_t)nRead, stored.data(), (uint64_t)windowsRead, 0, &first);
+    if (rc != OZCS_OK) throw OzoneChecksumException(std::string(ozcs_last_error()));
+    if (first >= 0) {
+      const size_t woff = (size_t)(first * bpc), wlen = (size_t)std::min(bpc, nRead - first * bpc);
+      const ChecksumData actual = Checksum(type, (int)bpc).computeChecksum(data.data() + woff, wlen);
+      throw OzoneChecksumException("Inconsistent read for chunk=" + chunkInfoToString(chunkName, chunkOffset, chunkLen) +
+                                   " checksum item " + std::to_string(first) + " expected checksum " +
+                                   javaBytesToString(sums[(size_t)first]) + " actual checksum " +
+                                   javaBytesToString(actual.getChecksums().at(0)) + " for block " + blockId);
+    }
+  }
+  if (nRead != chunkLen)
+    throw OzoneChecksumException("Inconsistent read for chunk=" + chunkName + " expected length=" + std::to_string(chunkLen) +
+                                 " actual length=" + std::to_string(nRead) + " for block " + blockId);
+  return nRead;
+}
+
+// ---------------------------------------------------------------------------------------------- write path
+
+// The chunk buffers of a BlockOutputStream as pinned pipe slots: allocateBuffer() hands out a pinned buffer
+// for the application's bytes (BufferPool.java:74-85), writeChunk() queues copy + checksum + copy-back and
+// returns at once (where the reference computes the checksum synchronously, BlockOutputStream.java:645-656),
+// and checksumOf() delivers the ChecksumData that goes into the chunk's ChunkInfo before writeChunkAsync.
+class PinnedChunkPool {
+ public:
+  PinnedChunkPool(int device, uint32_t capacity, uint64_t bufferSize, ChecksumType type, int bytesPerChecksum)
+      : type_(type), bpc_(bytesPerChecksum), outs_(capacity) {
+    const int rc = ozcs_pipe_create(device, capacity, bufferSize, &pipe_);
+    if (rc != OZCS_OK) throw GpuUnavailable(rc, std::string("ozcs_pipe_create: ") + ozcs_last_error());
+  }
+  ~PinnedChunkPool() { ozcs_pipe_destroy(pipe_); }
+  PinnedChunkPool(const PinnedChunkPool&) = delete;
+  PinnedChunkPool& operator=(const PinnedChunkPool&) = delete;
+
+  uint64_t getBufferSize() const { return ozcs_pipe_slot_bytes(pipe_); }
+
+  // A free pinned buffer and its ticket, or {nullptr, -1} when every buffer is held (the reference blocks in
+  // waitOnFlushFutures then; here the caller finishes one of its tickets with checksumOf()).
+  std::pair<void*, int> allocateBuffer() {
+    void* buf = nullptr;
+    int ticket = -1;
+    const int rc = ozcs_pipe_acquire(pipe_, &buf, &ticket);
+    if (rc == OZCS_EBUSY) return {nullptr, -1};
+    if (rc != OZCS_OK) throw GpuUnavailable(rc, std::string("ozcs_pipe_acquire: ") + ozcs_last_error());
+    return {buf, ticket};
+  }
+
+  // The first `len` bytes of the ticket's buffer are the chunk: start copy + checksum + copy-back.
+  void writeChunk(int ticket, uint64_t len) {
+    const int t = (int)type_;
+    const uint64_t n = type_ == ChecksumType::NONE ? 0 : ozcs_num_checksums(len, (uint32_t)bpc_);
+    outs_.at((size_t)ticket).assign((size_t)(n * ozcs_digest_size(t)), '\0');
+    std::string& o = outs_[(size_t)ticket];
+    const int rc = ozcs_pipe_submit_slot(pipe_, ticket, t, (uint32_t)bpc_, len, o.empty() ? nullptr : &o[0], o.size());
+    if (rc == OZCS_EINVAL && (t < OZCS_NONE || t > OZCS_MD5)) throw OzoneChecksumException(type_);
+    if (rc != OZCS_OK) throw GpuUnavailable(rc, std::string("ozcs_pipe_submit_slot: ") + ozcs_last_error());
+  }
+
+  // Blocks until the ticket's digests are back; the buffer returns to the pool (releaseBuffer).
+  ChecksumData checksumOf(int ticket) {
+    uint64_t n = 0;
+    const int rc = ozcs_pipe_wait(pipe_, ticket, &n);
+    if (rc != OZCS_OK) throw GpuUnavailable(rc, std::string("ozcs_pipe_wait: ") + ozcs_last_error());
+    const std::string& raw = outs_.at((size_t)ticket);
+    const size_t ds = ozcs_digest_size((int)type_);
+    std::vector<ByteString> v;
+    for (uint64_t i = 0; i < n; i++) v.emplace_back(raw.substr((size_t)i * ds, ds));
+    return ChecksumData(type_, bpc_, std::move(v));
+  }
+
+ private:
+  ozcs_pipe* pipe_ = nullptr;
+  ChecksumType type_;
+  int bpc_;
+  std::vector<std::string> outs_;  // per ticket: where the pipe delivers the digests
+};
+
+}  // namespace ozone

@@ -95,10 +95,51 @@ class ChecksumData {
     return out;
   }
 
+  // ChecksumData.getFromProtoBuf (ChecksumData.java:94-102) from the serialised message: fields 1 (type,
+  // varint), 2 (bytesPerChecksum, varint) and 3 (checksums, repeated bytes); other fields are skipped.
+  static ChecksumData getFromProtoBuf(const ByteString& msg) {
+    int type = 0;
+    uint64_t bpc = 0;
+    std::vector<ByteString> sums;
+    size_t i = 0;
+    while (i < msg.size()) {
+      const uint64_t key = getVarint(msg, i);
+      const uint64_t field = key >> 3, wire = key & 7;
+      if (wire == 0) {
+        const uint64_t v = getVarint(msg, i);
+        if (field == 1) type = (int)v;
+        if (field == 2) bpc = v;
+      } else if (wire == 2) {
+        const uint64_t n = getVarint(msg, i);
+        if (n > msg.size() - i) throw std::invalid_argument("ChecksumData: truncated message");
+        if (field == 3) sums.emplace_back(msg.substr(i, (size_t)n));
+        i += (size_t)n;
+      } else if (wire == 1) {
+        i += 8;
+      } else if (wire == 5) {
+        i += 4;
+      } else {
+        throw std::invalid_argument("ChecksumData: unsupported wire type");
+      }
+    }
+    if (i != msg.size()) throw std::invalid_argument("ChecksumData: truncated message");
+    return ChecksumData((ChecksumType)type, (int)bpc, std::move(sums));
+  }
+
  private:
   static void putVarint(ByteString& o, uint64_t v) {
     while (v >= 0x80) { o.push_back((char)(v | 0x80)); v >>= 7; }
     o.push_back((char)v);
+  }
+  static uint64_t getVarint(const ByteString& m, size_t& i) {
+    uint64_t v = 0;
+    for (int shift = 0; shift < 64; shift += 7) {
+      if (i >= m.size()) throw std::invalid_argument("ChecksumData: truncated varint");
+      const uint8_t b = (uint8_t)m[i++];
+      v |= (uint64_t)(b & 0x7f) << shift;
+      if (!(b & 0x80)) return v;
+    }
+    throw std::invalid_argument("ChecksumData: varint too long");
   }
   ChecksumType type_;
   int bytesPerChecksum_;

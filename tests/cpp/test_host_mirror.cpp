@@ -3,10 +3,12 @@
 // how a JNI host would load the library.  Exit code 0 = all passed.
 #include <cstdio>
 #include <cstring>
+#include <unistd.h>
+#include <utility>
 #include <string>
 #include <vector>
 
-#include "../../hadoop-ozone_amd/host/ozone_checksum.hpp"
+#include "../../hadoop-ozone_amd/host/ozone_callers.hpp"
 #include "../../oracle/ozcs_oracle.h"
 
 using namespace ozone;
@@ -87,6 +89,106 @@ int main() {
   oracle_fill_splitmix64(1, (uint8_t*)&chunk[0], chunk.size());
   for (ChecksumType t : types)
     EXPECT(Checksum(t, 1 << 20).computeChecksum(chunk.data(), chunk.size()).getChecksums() == oracle_sums(t, 1 << 20, chunk));
+  // proto round trip (ChecksumData.java:78-102)
+  EXPECT(ChecksumData::getFromProtoBuf(one.getProtoBufMessage()) == one);
+  EXPECT(ChecksumData::getFromProtoBuf(cd.getProtoBufMessage()) == cd);
+  try {
+    ChecksumData::getFromProtoBuf(one.getProtoBufMessage().substr(0, 9));
+    EXPECT(!"truncated message accepted");
+  } catch (const std::invalid_argument&) {}
+
+  // ---- read path: TestChunkInputStream shapes (100-byte chunk, 20 bytes per checksum) ----
+  EXPECT(computeChecksumBoundaries(25, 30, 20, 100) == std::make_pair(20LL, 40LL));   // bytes 25..54 -> 20..59
+  EXPECT(computeChecksumBoundaries(0, 100, 20, 100) == std::make_pair(0LL, 100LL));
+  EXPECT(computeChecksumBoundaries(95, 5, 20, 100) == std::make_pair(80LL, 20LL));
+  EXPECT(computeChecksumBoundaries(70, 30, 20, 95) == std::make_pair(60LL, 35LL));   // capped at the chunk length
+  {
+    const auto range = computeChecksumBoundaries(25, 30, 20, 100);
+    const std::string resp = whole.substr((size_t)range.first, (size_t)range.second);
+    validateReadChunk("chunk1", 0, cd, range.first, range.second, {resp}, true);                        // V0
+    validateReadChunk("chunk1", 0, cd, range.first, range.second, {resp.substr(0, 20), resp.substr(20)}, false);  // V1
+    try {
+      validateReadChunk("chunk1", 0, cd, range.first, range.second, {resp.substr(0, 39)}, true);
+      EXPECT(!"short response accepted");
+    } catch (const OzoneChecksumException& e) {
+      EXPECT(std::string(e.what()) == "Inconsistent read for chunk=chunk1 len=40 bytesRead=39");
+    }
+    std::string flipped = resp;
+    flipped[25] ^= 1;   // second window of the response = window 2 of the chunk
+    try {
+      validateReadChunk("chunk1", 0, cd, range.first, range.second, {flipped}, true);
+      EXPECT(!"corrupt response accepted");
+    } catch (const OzoneChecksumException& e) { EXPECT(e.index() == 1); }
+  }
+
+  // ---- scrubber: TestKeyValueContainerCheck shape (SHA-256, ragged last window), both layouts ----
+  {
+    const int bpc = 2048;
+    const long long chunkLen = 3 * 2048 + 1024, chunkOffset = 5000;
+    std::string file(chunkOffset + chunkLen + 777, '\0');
+    oracle_fill_splitmix64(9, (uint8_t*)&file[0], file.size());
+    const std::string path = "/tmp/ozcs_cpp_chunk_" + std::to_string((long long)getpid());
+    auto put = [&](const std::string& bytes) {
+      FILE* f = std::fopen(path.c_str(), "wb");
+      std::fwrite(bytes.data(), 1, bytes.size(), f);
+      std::fclose(f);
+    };
+    put(file);
+    const ChecksumData stored = Checksum(ChecksumType::SHA256, bpc).computeChecksum(file.data() + chunkOffset, (size_t)chunkLen);
+    std::vector<long long> seen;
+    EXPECT(verifyChunkFile("blk#1", "c1", chunkOffset, chunkLen, stored, path, ChunkLayOutVersion::FILE_PER_BLOCK,
+                           [&](long long n) { seen.push_back(n); }) == chunkLen);
+    EXPECT((seen == std::vector<long long>{2048, 2048, 2048, 1024}));
+    std::string bad = file;
+    bad[(size_t)chunkOffset + 2048 + 7] ^= 0x40;
+    put(bad);
+    try {
+      verifyChunkFile("blk#1", "c1", chunkOffset, chunkLen, stored, path, ChunkLayOutVersion::FILE_PER_BLOCK);
+      EXPECT(!"corrupt chunk accepted");
+    } catch (const OzoneChecksumException& e) {
+      const std::string w = e.what();
+      EXPECT(w.find("Inconsistent read for chunk=ChunkInfo{chunkName='c1, offset=5000, len=7168} checksum item 1 expected checksum [") == 0);
+      EXPECT(w.find(" for block blk#1") == w.size() - 16);
+    }
+    put(file.substr(0, (size_t)chunkOffset + 4096));   // truncated at a window boundary
+    try {
+      verifyChunkFile("blk#1", "c1", chunkOffset, chunkLen, stored, path, ChunkLayOutVersion::FILE_PER_BLOCK);
+      EXPECT(!"truncated chunk accepted");
+    } catch (const OzoneChecksumException& e) {
+      EXPECT(std::string(e.what()) == "Inconsistent read for chunk=c1 expected length=7168 actual length=4096 for block blk#1");
+    }
+    put(file.substr((size_t)chunkOffset, (size_t)chunkLen));   // FILE_PER_CHUNK: the file is the chunk
+    EXPECT(verifyChunkFile("blk#1", "c1", chunkOffset, chunkLen, stored, path, ChunkLayOutVersion::FILE_PER_CHUNK) == chunkLen);
+    std::remove(path.c_str());
+  }
+
+  // ---- write path: chunks through pinned buffers, checksum overlapped with the next fill ----
+  {
+    PinnedChunkPool pool(0, 3, 1 << 20, ChecksumType::CRC32C, 65536);
+    EXPECT(pool.getBufferSize() == (1u << 20));
+    std::vector<std::pair<int, std::string>> inflight;
+    int checked = 0;
+    for (int i = 0; i < 10; i++) {
+      std::pair<void*, int> b = pool.allocateBuffer();
+      if (!b.first) {   // every buffer held: finish the oldest chunk, as BufferPool makes the writer wait
+        EXPECT(pool.checksumOf(inflight.front().first).getChecksums() == oracle_sums(ChecksumType::CRC32C, 65536, inflight.front().second));
+        inflight.erase(inflight.begin());
+        checked++;
+        b = pool.allocateBuffer();
+      }
+      EXPECT(b.first != nullptr);
+      std::string bytes((1u << 20) - 1000 * i, '\0');
+      oracle_fill_splitmix64(100 + i, (uint8_t*)&bytes[0], bytes.size());
+      std::memcpy(b.first, bytes.data(), bytes.size());
+      pool.writeChunk(b.second, bytes.size());
+      inflight.emplace_back(b.second, bytes);
+    }
+    for (auto& f : inflight) {
+      EXPECT(pool.checksumOf(f.first).getChecksums() == oracle_sums(ChecksumType::CRC32C, 65536, f.second));
+      checked++;
+    }
+    EXPECT(checked == 10);
+  }
   std::printf(failures ? "%d FAILURES\n" : "host mirror: all passed\n", failures);
   ozcs_shutdown();
   return failures ? 1 : 0;
