@@ -195,6 +195,9 @@ def main():
                          "kernel_ms_avg": round(avg_kernel_s * 1e3, 4), "kernel_ms_min": round(min(kernel_ms), 4),
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
+        if args.type in ("SHA256", "MD5"):
+            out["roofline"]["note"] = ("integer-VALU bound (one lane per window, ~22 / ~5 vector instructions per byte); "
+                                       "the HBM fraction is reported because the metric asks for it")
         if world == 1 and not args.no_cpu_baseline and args.type == "CRC32" and args.mode == "compute":
             sample = data[: min(nbytes, 2 << 30)].cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(sample, args.bpc)
