@@ -606,3 +606,27 @@ def test_pipe_shared_by_threads(gpu):
         assert not errors, errors
     finally:
         L.ozcs_pipe_destroy(pipe)
+
+
+def test_largest_windows_and_offsets_beyond_4_gib(gpu):
+    # bytesPerChecksum is a Java int: windows of hundreds of MiB, and a chunk whose offsets need 64 bits
+    torch, native, L = gpu
+    GIB = 1 << 30
+    host = oracle.splitmix64(31337, 5 * GIB + 12345)
+    d = torch.from_numpy(host).cuda()
+    # CRC: 1 GiB - 1 windows over 5 GiB + 12345 bytes (six windows, the last one short, unaligned starts)
+    for t in (oracle.CRC32, oracle.CRC32C):
+        bpc = GIB - 1
+        assert dev_compute(gpu, t, bpc, d, host.size, 1, host.size) == oracle.compute(t, bpc, host)
+    # the largest bytesPerChecksum an int holds: one window covering 2 GiB - 1 bytes, then the rest
+    bpc = (1 << 31) - 1
+    assert dev_compute(gpu, oracle.CRC32, bpc, d, host.size, 1, host.size) == oracle.compute(oracle.CRC32, bpc, host)
+    # two chunks 2.5 GiB apart: the second chunk's windows lie beyond 4 GiB
+    stride = 5 * GIB // 2
+    assert dev_compute(gpu, oracle.CRC32C, 1 << 20, d, 3 * MIB + 5, 2, stride) == oracle_chunks(oracle.CRC32C, 1 << 20, host, 3 * MIB + 5, 2, stride)
+    # digests: one lane walks a 200 MiB window (MD5) / a 48 MiB window (SHA-256)
+    sub = d[4 * GIB + 3: 4 * GIB + 3 + 500 * MIB]
+    hsub = host[4 * GIB + 3: 4 * GIB + 3 + 500 * MIB]
+    assert dev_compute(gpu, oracle.MD5, 200 * MIB + 1, sub, hsub.size, 1, hsub.size) == oracle.compute(oracle.MD5, 200 * MIB + 1, hsub)
+    assert dev_compute(gpu, oracle.SHA256, 48 * MIB - 7, sub[: 100 * MIB], 100 * MIB, 1, 100 * MIB) == \
+        oracle.compute(oracle.SHA256, 48 * MIB - 7, hsub[: 100 * MIB])
