@@ -630,3 +630,33 @@ def test_largest_windows_and_offsets_beyond_4_gib(gpu):
     assert dev_compute(gpu, oracle.MD5, 200 * MIB + 1, sub, hsub.size, 1, hsub.size) == oracle.compute(oracle.MD5, 200 * MIB + 1, hsub)
     assert dev_compute(gpu, oracle.SHA256, 48 * MIB - 7, sub[: 100 * MIB], 100 * MIB, 1, 100 * MIB) == \
         oracle.compute(oracle.SHA256, 48 * MIB - 7, hsub[: 100 * MIB])
+
+
+def test_compute_batch_random_sweep(gpu):
+    # 500 chunks of random type, window size and length in ONE ozcs_compute_batch call (more than one job list
+    # per digest type, chunks of one byte, windows of one byte, lengths around every block and stripe boundary)
+    torch, native, L = gpu
+    rng = np.random.default_rng(2024)
+    n = 500
+    arr = (native.OzcsChunk * n)()
+    specs, bufs, outs = [], [], []
+    edge = [1, 2, 3, 4, 5, 15, 16, 17, 55, 56, 57, 63, 64, 65, 119, 120, 127, 128, 129, 1023, 1024, 1025, 4095, 4096, 4097]
+    for i in range(n):
+        t = int(rng.choice([oracle.CRC32, oracle.CRC32C, oracle.SHA256, oracle.MD5]))
+        bpc = int(rng.choice([1, 7, 10, 64, 100, 512, 1000, 4096, 16384, 65536]))
+        ln = int(rng.choice(edge)) if i % 3 == 0 else int(rng.integers(1, min(60 * bpc, 300000) + 1))
+        if bpc < 8:
+            ln = min(ln, 2000)
+        b = oracle.splitmix64(7000 + i, ln)
+        ds = native.DIGEST_SIZE[t]
+        o = ctypes.create_string_buffer(((ln + bpc - 1) // bpc) * ds)
+        specs.append((t, bpc, ln))
+        bufs.append(b)
+        outs.append(o)
+        arr[i].data, arr[i].len = b.ctypes.data, ln
+        arr[i].sums, arr[i].sums_cap = ctypes.cast(o, ctypes.c_void_p).value, len(o)
+        arr[i].bpc, arr[i].type = bpc, t
+    native.check(L.ozcs_compute_batch(arr, n))
+    for i, (t, bpc, ln) in enumerate(specs):
+        assert arr[i].status == native.OK, (i, t, bpc, ln)
+        assert outs[i].raw == oracle.compute(t, bpc, bufs[i]), (i, t, bpc, ln)
