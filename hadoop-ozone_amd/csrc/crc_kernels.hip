@@ -485,6 +485,133 @@ __global__ __launch_bounds__(kThreads) void crc_subwave_kernel(const CrcLaunch p
   }
 }
 
+// The small-window kernel for the plainest layout: every window is a full bpc bytes, windows follow one
+// another without gaps (chunks back to back, chunk length a multiple of bpc), everything 16-byte aligned and
+// bpc a multiple of UNR stripes.  Then window g is simply [data + g*bpc, +bpc), every lane runs the same
+// number of stripes, nothing is masked and nothing is left for the bit-serial tail: the per-window
+// bookkeeping, a quarter of the instructions at 512-byte windows, shrinks to one multiply-add.
+// Lanes past the last window redo the last window and store nothing.
+//
+// Stripes are loaded UNR at a time.  The inner loop costs the same per byte whatever the stripe size, but
+// the fold costs one operator application per accumulator, so few lanes per window (a short stripe) would
+// make small windows cheaper -- if the memory path kept up: 4 lanes per window read 64-byte pieces and reach
+// 4.1 TB/s at 512-byte windows, 5.3 with the two halves of a line requested by adjacent instructions
+// (UNR = 2), against 5.8 for 8 lanes (profiles/r01_crc_flat_sweep.log).  UNR = 2 is used where it measured
+// faster: windows of 256 bytes and less.
+template <int LPW, int MODE, int UNR>
+__global__ __launch_bounds__(kThreads) void crc_flat_kernel(const CrcLaunch p) {
+  __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
+  constexpr uint32_t kStripe = 16u * LPW;
+  constexpr int kWinPerRow = 64 / LPW;
+  constexpr int kWinPerWave = 2 * kWinPerRow;
+  constexpr int kLevels = LPW == 4 ? 2 : LPW == 8 ? 3 : LPW == 16 ? 4 : 5;
+  constexpr int kMainOp = kOpZ16 + kLevels;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  build_tables(lds, c_basis[p.poly_idx], kMainOp, tid);
+  __syncthreads();
+
+  const uint32_t lb01 = (uint32_t)(lane & 31) * 4u;
+  const uint32_t lb23 = lb01 + 65536u;
+  const int sl = lane & (LPW - 1);
+  const int grp = lane / LPW;
+  const uint32_t nst = p.bpc / kStripe;  // a multiple of UNR
+  const uint32_t init = sl == 0 ? 0xFFFFFFFFu : 0u;  // the window's first four bytes are lane 0's first dword
+  const uintptr_t base = reinterpret_cast<uintptr_t>(p.data) + 16u * sl;
+  const uint64_t last = p.n_windows - 1;
+
+  for (uint64_t w0 = ((uint64_t)blockIdx.x * kWaves + wave) * kWinPerWave; w0 < p.n_windows;
+       w0 += (uint64_t)gridDim.x * kWaves * kWinPerWave) {
+    const uint64_t ga = w0 + grp, gb = w0 + kWinPerRow + grp;
+    uintptr_t ua = base + (ga < last ? ga : last) * p.bpc, ub = base + (gb < last ? gb : last) * p.bpc;
+    uint4 ca[UNR], cb[UNR], na[UNR], nb[UNR];
+#pragma unroll
+    for (int k = 0; k < UNR; k++) {
+      ca[k] = ld16(ua + k * kStripe);
+      cb[k] = ld16(ub + k * kStripe);
+    }
+    if (nst > UNR) {
+      ua += UNR * kStripe;
+      ub += UNR * kStripe;
+#pragma unroll
+      for (int k = 0; k < UNR; k++) {
+        na[k] = ld16(ua + k * kStripe);
+        nb[k] = ld16(ub + k * kStripe);
+      }
+    }
+    Acc4 a = {ca[0].x ^ init, ca[0].y, ca[0].z, ca[0].w}, b = {cb[0].x ^ init, cb[0].y, cb[0].z, cb[0].w};
+#pragma unroll
+    for (int k = 1; k < UNR; k++) {
+      absorb(lds, lb01, lb23, a, ca[k]);
+      absorb(lds, lb01, lb23, b, cb[k]);
+    }
+    for (uint32_t j = UNR; j < nst; j += UNR) {
+#pragma unroll
+      for (int k = 0; k < UNR; k++) {
+        ca[k] = na[k];
+        cb[k] = nb[k];
+      }
+      if (j + UNR < nst) {
+        ua += UNR * kStripe;
+        ub += UNR * kStripe;
+#pragma unroll
+        for (int k = 0; k < UNR; k++) {
+          na[k] = ld16(ua + k * kStripe);
+          nb[k] = ld16(ub + k * kStripe);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < UNR; k++) {
+        absorb(lds, lb01, lb23, a, ca[k]);
+        absorb(lds, lb01, lb23, b, cb[k]);
+      }
+    }
+    uint32_t x = slot_fold(lds, a), y = slot_fold(lds, b);
+#pragma unroll
+    for (int i = 0; i < kLevels; i++) {  // as in crc_subwave_kernel
+      const bool taker = (sl & ((2 << i) - 1)) == (2 << i) - 1;
+      const uint32_t below = lanes_up(x, i);
+      const uint32_t t = nib_apply(lds, kOpZ16 + i, taker ? below : y);
+      x ^= t;
+      y ^= lanes_up(t, i);
+    }
+    if (sl == LPW - 1) {
+      if (MODE == kModeCompute) {  // sums is 4-byte aligned in this layout (checked by the launcher)
+        uint32_t* out = reinterpret_cast<uint32_t*>(p.sums);
+        if (ga <= last) out[ga] = __builtin_bswap32(~x);
+        if (gb <= last) out[gb] = __builtin_bswap32(~y);
+      } else {
+        uint64_t chunk, wi;
+        if (ga <= last) {
+          split_window(p, ga, chunk, wi);
+          emit<MODE>(p, ga, chunk, wi, __builtin_bswap32(~x));
+        }
+        if (gb <= last) {
+          split_window(p, gb, chunk, wi);
+          emit<MODE>(p, gb, chunk, wi, __builtin_bswap32(~y));
+        }
+      }
+    }
+  }
+}
+
+// (lanes per window, stripes per load group) pairs that are built
+template <int MODE>
+hipError_t launch_flat(const CrcLaunch& p, int lpw, int unr, int blocks, hipStream_t stream) {
+  switch (lpw * 8 + unr) {
+    case 4 * 8 + 1: crc_flat_kernel<4, MODE, 1><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 4 * 8 + 2: crc_flat_kernel<4, MODE, 2><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 8 * 8 + 1: crc_flat_kernel<8, MODE, 1><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 8 * 8 + 2: crc_flat_kernel<8, MODE, 2><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 16 * 8 + 1: crc_flat_kernel<16, MODE, 1><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 32 * 8 + 1: crc_flat_kernel<32, MODE, 1><<<blocks, kThreads, 0, stream>>>(p); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
 template <int MODE, bool AL>
 hipError_t launch_subwave(const CrcLaunch& p, int lpw, int blocks, hipStream_t stream) {
   switch (lpw) {
@@ -519,6 +646,8 @@ const int g_force_group = env_int("OZCS_CRC_GROUP");
 const int g_force_pf = env_int("OZCS_CRC_PF");
 const int g_force_lpw = env_int("OZCS_CRC_LPW");  // 4|8|16|32 lanes per window, 64 = never use the small-window kernel
 const int g_no_aligned = env_int("OZCS_CRC_NO_ALIGNED");  // 1 = always take the any-alignment code path
+const int g_no_flat = env_int("OZCS_CRC_NO_FLAT");        // 1 = never take the gapless-full-windows kernel
+const int g_force_flat = env_int("OZCS_CRC_FLAT");        // lanes * 8 + stripes per load group, e.g. 34 = 4 lanes, 2 stripes
 
 }  // namespace
 
@@ -565,6 +694,26 @@ hipError_t crc_launch(const CrcLaunch& launch, int mode, int group, int num_cus,
     if (nb > (uint64_t)num_cus) nb = num_cus;
     // every window starts on a 16-byte boundary: the masking of partial leading units is not needed
     const bool aligned = !g_no_aligned && ((reinterpret_cast<uintptr_t>(p.data) | p.chunk_stride | p.bpc) & 15u) == 0;
+    // full windows back to back, a whole number of load groups each, digests storable as aligned words
+    const bool gapless = aligned && !g_no_flat && p.chunk_len % p.bpc == 0 &&
+                         (p.chunk_stride == p.chunk_len || p.n_windows == p.wpc) &&
+                         (mode != kModeCompute || (reinterpret_cast<uintptr_t>(p.sums) & 3u) == 0);
+    if (gapless) {
+      int fl = lpw, fu = (p.bpc <= 256 && p.bpc % (32u * lpw) == 0) ? 2 : 1;
+      if (g_force_flat > 0) {
+        fl = g_force_flat / 8;
+        fu = g_force_flat % 8;
+      }
+      if (p.bpc % (16u * fl * fu) == 0) {
+        const uint64_t per = (uint64_t)kWaves * 2 * (64 / fl);
+        uint64_t fb = (p.n_windows + per - 1) / per;
+        if (fb > (uint64_t)num_cus) fb = num_cus;
+        const hipError_t e = mode == kModeCompute ? launch_flat<kModeCompute>(p, fl, fu, (int)fb, stream)
+                                                  : launch_flat<kModeVerify>(p, fl, fu, (int)fb, stream);
+        if (e != hipErrorInvalidValue) return e;
+        (void)hipGetLastError();  // that (lanes, group) pair is not built: use the general kernel
+      }
+    }
     if (aligned)
       return mode == kModeCompute ? launch_subwave<kModeCompute, true>(p, lpw, (int)nb, stream)
                                   : launch_subwave<kModeVerify, true>(p, lpw, (int)nb, stream);

@@ -110,6 +110,12 @@ CRC_SHAPES = [
     (33, MIB + 48, MIB + 48, 1024),
     (20, 256 * 1024 + 17, 256 * 1024 + 32, 256),
     (300, 65536 + 3, 65536 + 16, 64),
+    # full windows back to back (the gapless-layout kernel), window counts that leave the last wavefront ragged
+    (37, 512 * 1024, 512 * 1024, 512),
+    (1, 33 * MIB + 1024, 33 * MIB + 1024, 1024),
+    (5, 5 * MIB, 5 * MIB, 4096),
+    (64, 4 * MIB, 4 * MIB, 16384),
+    (3, 4 * MIB, 4 * MIB, 256),
 ]
 
 
