@@ -20,10 +20,16 @@
 //     two independent dependency chains, which keeps the LDS pipeline fed.
 //   * At the end of a window the accumulators are one stripe-sized message with the same CRC
 //     as the window.  It is folded with fixed shift operators: 4 slots -> unit, 64 lanes -> row
-//     (prefix tree over __shfl_up), 2 rows -> wavefront, G wavefronts -> window (through LDS).
+//     (reduction tree over DPP row shifts), 2 rows -> wavefront, G wavefronts -> window (through LDS).
 //     These operators use 16-entry nibble tables (conflict-free without copies: 16 consecutive
 //     banks).
 //   * The at most 15 bytes behind the last aligned 16-byte boundary are finished bit-serially.
+//
+// Three kernels share that inner loop:
+//   crc_windows_kernel  G wavefronts per window (1..16), for windows above 256 KiB or scarce windows;
+//   crc_subwave_kernel  4..32 lanes per window, any alignment and ragged last windows;
+//   crc_flat_kernel     the same for the gapless layout (full, aligned windows back to back), where the
+//                       per-window geometry disappears.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
