@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""End-to-end host -> device -> host rate of the pinned pipeline (BASELINE config 5): 4 MiB chunks through
+"""End-to-end host -> device -> host rate of the pinned pipeline (the end-to-end write-path configuration): 4 MiB chunks through
 ozcs_pipe slots, CRC32 : MD5 = 3 : 1 at 1 MiB windows, H2D copy / kernel / digest copy-back on three streams.
 Prints one JSON line per variant.  PCIe-bound by design: this is NOT the headline device-resident number."""
 import ctypes

@@ -184,7 +184,7 @@ def main():
     add("TestKeyValueContainerCheck-3072-2048", SHA256, 2048, {"kind": "splitmix64", "seed": 3072, "len": 3072})
     # ContainerProtocolCalls.java:336-337 writeSmallFile shape: CRC32 at bpc 256
     add("writeSmallFile-1000-256", CRC32, 256, {"kind": "splitmix64", "seed": 256, "len": 1000})
-    # BASELINE config 1: one 4 MiB chunk at 1 MiB windows
+    # the unit-scale configuration: one 4 MiB chunk at 1 MiB windows
     for t in ALL:
         add("chunk4M-1M-%s" % NAMES[t], t, 1 << 20, {"kind": "splitmix64", "seed": 1, "len": 4 << 20})
     add("chunk4M-1M-zeros-CRC32", CRC32, 1 << 20, {"kind": "zeros", "len": 4 << 20})

@@ -257,7 +257,7 @@ def test_verify_k_corrupted_windows_at_speed(gpu):
 # ------------------------------------------------------------------ benchmark-sized properties
 
 def test_full_size_properties_crc32_1mib(gpu):
-    """8 GiB of 4 MiB chunks at 1 MiB windows (BASELINE config 2 with 32 blocks)."""
+    """8 GiB of 4 MiB chunks at 1 MiB windows (the headline configuration with 32 blocks)."""
     torch, native, L = gpu
     nbytes = 32 * 256 * MIB
     chunk = 4 * MIB
@@ -412,7 +412,7 @@ def test_reference_TestChecksum(gpu):
 # ------------------------------------------------------------------ asynchronous pinned pipeline
 
 def test_pipe_mixed_types_against_oracle(gpu):
-    # BASELINE config 5 in miniature: host -> device -> host through pinned slots, CRC32 : MD5 = 3 : 1
+    # the end-to-end write-path configuration in miniature: host -> device -> host through pinned slots, CRC32 : MD5 = 3 : 1
     torch, native, L = gpu
     pipe = ctypes.c_void_p()
     native.check(L.ozcs_pipe_create(0, 6, 4 * MIB, ctypes.byref(pipe)))
