@@ -53,24 +53,33 @@ def load_profile_traffic(workload):
 
 
 def cpu_baseline(sample, bpc):
-    """The oracle (C restatement of ChecksumByteBuffer.CrcIntTable.update, slice-by-8) timed on this
-    box's host cores over a bounded sample of the same workload.  Not the JVM."""
+    """The reference's CPU path restated in C and timed on this box's host cores over a bounded sample of the
+    same workload.  Not the JVM (none exists here).  Two engines: PCLMULQDQ folding, which is what the JDK's
+    java.util.zip.CRC32 intrinsic (the reference's production engine, ChecksumByteBufferFactory.java:74-76)
+    is built on -- the reported value; and the slice-by-8 restatement of the reference's own
+    ChecksumByteBuffer.CrcIntTable.update, which is also the parity oracle."""
     import zlib
     import oracle
     cores = min(16, os.cpu_count() or 1)
     n1 = min(sample.nbytes, 1 << 30)
     t1 = oracle.bench(oracle.CRC32, bpc, sample[:n1], threads=1, reps=2)
     tn = oracle.bench(oracle.CRC32, bpc, sample, threads=cores, reps=8)
+    c1 = oracle.bench_clmul(oracle.CRC32, bpc, sample[:n1], threads=1, reps=3)
+    cn = oracle.bench_clmul(oracle.CRC32, bpc, sample, threads=cores, reps=8)
     mv = memoryview(sample[: min(sample.nbytes, 256 * MIB)])
     t0 = time.perf_counter()
     for o in range(0, len(mv), bpc):
         zlib.crc32(mv[o:o + bpc])
     tz = time.perf_counter() - t0
     return {
-        "value": round(sample.nbytes / tn / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": "port",
-        "sample": "%d MiB of the same random bytes, CRC32 at %d B windows, best of 8 passes; C slice-by-8 "
-                  "restatement of the reference's CrcIntTable, not the JVM" % (sample.nbytes // MIB, bpc),
-        "one_core_GBps": round(n1 / t1 / 1e9, 3),
+        "value": round(sample.nbytes / cn / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": "port",
+        "sample": "%d MiB of the same random bytes, CRC32 at %d B windows, best of 8 passes on %d threads; C "
+                  "restatement (%s), not the JVM" % (sample.nbytes // MIB, bpc, cores,
+                                                    "PCLMULQDQ folding as in the JDK intrinsic" if oracle.has_clmul()
+                                                    else "table method: this CPU lacks PCLMULQDQ"),
+        "one_core_GBps": round(n1 / c1 / 1e9, 3),
+        "slice_by_8_GBps": round(sample.nbytes / tn / 1e9, 3),
+        "slice_by_8_one_core_GBps": round(n1 / t1 / 1e9, 3),
         "zlib_crc32_one_core_GBps": round(len(mv) / tz / 1e9, 3),
     }
 

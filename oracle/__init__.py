@@ -54,6 +54,13 @@ def lib():
         L.oracle_bench.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64,
                                    ctypes.c_int, ctypes.c_int]
         L.oracle_bench.restype = ctypes.c_double
+        L.oracle_bench_clmul.argtypes = L.oracle_bench.argtypes
+        L.oracle_bench_clmul.restype = ctypes.c_double
+        L.oracle_has_clmul.argtypes = []
+        L.oracle_has_clmul.restype = ctypes.c_int
+        L.oracle_compute_clmul.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64,
+                                           ctypes.c_void_p, ctypes.c_uint64]
+        L.oracle_compute_clmul.restype = ctypes.c_int64
         _lib = L
     return _lib
 
@@ -124,3 +131,24 @@ def verify(type_, bpc, data, stored, start_index=0):
 def bench(type_, bpc, data, threads=1, reps=3):
     addr, n, keep = _buf(data)
     return lib().oracle_bench(type_, bpc, addr, n, threads, reps)
+
+
+def has_clmul():
+    """True when the CPU-baseline CRC runs on PCLMULQDQ (else it falls back to the table method)."""
+    return bool(lib().oracle_has_clmul())
+
+
+def compute_clmul(type_, bpc, data):
+    """compute() for CRC32 / CRC32C through the carry-less-multiply folding of crc_clmul.c (the CPU baseline)."""
+    addr, n, keep = _buf(data)
+    nwin = (n + bpc - 1) // bpc if bpc else 0
+    out = ctypes.create_string_buffer(max(1, nwin * 4))
+    rc = lib().oracle_compute_clmul(type_, bpc, addr, n, out, nwin * 4)
+    if rc < 0:
+        raise ValueError("oracle_compute_clmul rejected type=%r bpc=%r" % (type_, bpc))
+    return out.raw[: rc * 4]
+
+
+def bench_clmul(type_, bpc, data, threads=1, reps=3):
+    addr, n, keep = _buf(data)
+    return lib().oracle_bench_clmul(type_, bpc, addr, n, threads, reps)

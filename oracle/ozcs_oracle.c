@@ -268,12 +268,13 @@ void oracle_fill_splitmix64(uint64_t seed, uint8_t *out, uint64_t len) {
 /* ------------------------------------------------------------ benchmark -- */
 
 typedef struct {
-  int type; uint32_t bpc; const uint8_t *data; uint64_t len; uint8_t *sums; uint64_t cap;
+  int type; uint32_t bpc; const uint8_t *data; uint64_t len; uint8_t *sums; uint64_t cap; int clmul;
 } bench_job;
 
 static void *bench_worker(void *arg) {
   bench_job *j = (bench_job *)arg;
-  oracle_compute(j->type, j->bpc, j->data, j->len, j->sums, j->cap);
+  if (j->clmul) oracle_compute_clmul(j->type, j->bpc, j->data, j->len, j->sums, j->cap);
+  else oracle_compute(j->type, j->bpc, j->data, j->len, j->sums, j->cap);
   return NULL;
 }
 
@@ -283,7 +284,18 @@ static double now_s(void) {
   return ts.tv_sec + 1e-9 * ts.tv_nsec;
 }
 
+static double bench_run(int type, uint32_t bpc, const uint8_t *data, uint64_t len, int threads, int reps, int clmul);
+
 double oracle_bench(int type, uint32_t bpc, const uint8_t *data, uint64_t len, int threads, int reps) {
+  return bench_run(type, bpc, data, len, threads, reps, 0);
+}
+
+double oracle_bench_clmul(int type, uint32_t bpc, const uint8_t *data, uint64_t len, int threads, int reps) {
+  if (type != ORACLE_CRC32 && type != ORACLE_CRC32C) return -1.0;
+  return bench_run(type, bpc, data, len, threads, reps, 1);
+}
+
+static double bench_run(int type, uint32_t bpc, const uint8_t *data, uint64_t len, int threads, int reps, int clmul) {
   if (threads < 1) threads = 1;
   if (threads > 256) threads = 256;
   const size_t ds = oracle_digest_size(type);
@@ -300,7 +312,7 @@ double oracle_bench(int type, uint32_t bpc, const uint8_t *data, uint64_t len, i
       uint64_t w1 = nwin * (uint64_t)(t + 1) / (uint64_t)threads;
       uint64_t b0 = w0 * bpc, b1 = w1 * bpc;
       if (b1 > len) b1 = len;
-      jobs[t] = (bench_job){type, bpc, data + b0, b1 - b0, sums + w0 * ds, (w1 - w0) * ds};
+      jobs[t] = (bench_job){type, bpc, data + b0, b1 - b0, sums + w0 * ds, (w1 - w0) * ds, clmul};
       w0 = w1;
       if (threads > 1) pthread_create(&th[t], NULL, bench_worker, &jobs[t]);
       else bench_worker(&jobs[t]);

@@ -102,6 +102,14 @@ void oracle_fill_splitmix64(uint64_t seed, uint8_t *out, uint64_t len);
 double oracle_bench(int type, uint32_t bpc, const uint8_t *data, uint64_t len,
                     int threads, int reps);
 
+/* crc_clmul.c: the same CRCs by PCLMULQDQ folding (what the JDK's CRC32 / CRC32C intrinsics are built on), for
+ * the benchmark's CPU baseline; falls back to the table method where the instruction is missing. */
+int oracle_has_clmul(void);
+uint32_t oracle_crc_clmul(int type, const uint8_t *data, size_t len);
+int64_t oracle_compute_clmul(int type, uint32_t bpc, const uint8_t *data, uint64_t len, uint8_t *out, uint64_t cap);
+/* oracle_bench with oracle_compute_clmul as the worker (CRC types only). */
+double oracle_bench_clmul(int type, uint32_t bpc, const uint8_t *data, uint64_t len, int threads, int reps);
+
 #ifdef __cplusplus
 }
 #endif

@@ -104,3 +104,19 @@ def test_random_against_zlib_hashlib():
         assert oracle.compute(oracle.SHA256, bpc, d) == exp
         exp = b"".join(hashlib.md5(b[o:o + bpc]).digest() for o in range(0, n, bpc))
         assert oracle.compute(oracle.MD5, bpc, d) == exp
+
+
+def test_clmul_baseline_engine_equals_the_oracle(vectors):
+    # the PCLMULQDQ engine timed as the CPU baseline must give the oracle's digests (it falls back to the table
+    # method on a CPU without the instruction, so this holds everywhere)
+    rng = np.random.default_rng(12)
+    for rec in vectors["compute"]:
+        if rec["type"] in (oracle.CRC32, oracle.CRC32C):
+            assert oracle.compute_clmul(rec["type"], rec["bpc"], make_data(rec["data"])).hex() == "".join(rec["sums_hex"]), rec["name"]
+    for i in range(120):
+        n = int(rng.choice([0, 1, 15, 16, 17, 63, 64, 65, 79, 80, 127, 128, 129, 191, 192, 1000, 4097, int(rng.integers(0, 200000))]))
+        off = int(rng.integers(0, 17))
+        d = oracle.splitmix64(900 + i, n + off)[off:]
+        for t in (oracle.CRC32, oracle.CRC32C):
+            bpc = int(rng.choice([64, 100, 4096, 1 << 20]))
+            assert oracle.compute_clmul(t, bpc, d) == oracle.compute(t, bpc, d), (t, bpc, n, off)
