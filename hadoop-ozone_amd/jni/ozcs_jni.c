@@ -7,6 +7,8 @@
  *
  * Heap arrays are reached with GetPrimitiveArrayCritical (no copy on HotSpot; the library then stages
  * the bytes to the device), direct buffers with GetDirectBufferAddress.  Nothing calls back into the JVM.
+ * The critical section spans the whole synchronous call, as in Hadoop's NativeCrc32 (about 0.2 ms for a
+ * 4 MiB chunk); callers with very large arrays should use the pinned pipe (direct buffers) instead.
  */
 #include <jni.h>
 #include <stdint.h>
@@ -25,6 +27,7 @@ JNIEXPORT jlong JNICALL JFN(calculateChunkedSumsByteArray)(JNIEnv* env, jclass c
   (void)cls;
   if (bpc <= 0 || dataLen < 0 || dataOff < 0 || sumsOff < 0) return OZCS_EINVAL;
   const jsize sumsLen = (*env)->GetArrayLength(env, sums);
+  if ((jlong)dataOff + dataLen > (*env)->GetArrayLength(env, data) || sumsOff > sumsLen) return OZCS_EINVAL;
   uint8_t* d = (uint8_t*)(*env)->GetPrimitiveArrayCritical(env, data, NULL);
   if (!d) return OZCS_ENOMEM;
   uint8_t* s = (uint8_t*)(*env)->GetPrimitiveArrayCritical(env, sums, NULL);
@@ -60,6 +63,11 @@ JNIEXPORT jlong JNICALL JFN(verifyChunkedSumsByteArray)(JNIEnv* env, jclass cls,
     jbyteArray sums, jint sumsOff, jint numSums, jint startIndex, jbyteArray data, jint dataOff, jint dataLen) {
   (void)cls;
   if (bpc <= 0 || dataLen < 0 || dataOff < 0 || sumsOff < 0 || numSums < 0 || startIndex < 0) return -1 + OZCS_EINVAL;
+  if ((jlong)dataOff + dataLen > (*env)->GetArrayLength(env, data)) return -1 + OZCS_EINVAL;
+  {
+    const jlong ds = (jlong)ozcs_digest_size(type);
+    if ((jlong)sumsOff + numSums * ds > (*env)->GetArrayLength(env, sums)) return -1 + OZCS_EINVAL;
+  }
   uint8_t* d = (uint8_t*)(*env)->GetPrimitiveArrayCritical(env, data, NULL);
   if (!d) return -1 + OZCS_ENOMEM;
   uint8_t* s = (uint8_t*)(*env)->GetPrimitiveArrayCritical(env, sums, NULL);
