@@ -116,6 +116,9 @@ CRC_SHAPES = [
     (5, 5 * MIB, 5 * MIB, 4096),
     (64, 4 * MIB, 4 * MIB, 16384),
     (3, 4 * MIB, 4 * MIB, 256),
+    (2, MIB, MIB, 128),
+    (2, MIB, MIB, 64),
+    (1, 3 * MIB, 3 * MIB, 48),      # not a whole number of stripes: the general aligned path
 ]
 
 
