@@ -31,6 +31,19 @@ struct CrcLaunch {
   unsigned long long* first_mismatch;
 };
 
+// One window on its own: `len` bytes at `data`, digest to `out` (device pointers).  A list of these describes a
+// batch of unrelated chunks (own sizes, own window sizes) for one launch.
+struct WindowDesc {
+  const uint8_t* data;
+  uint8_t* out;
+  uint32_t len;
+  uint32_t reserved;
+};
+
+// CRC of n described windows; total_bytes (the sum of their lengths) guides the choice of lanes per window.
+hipError_t crc_launch_desc(const WindowDesc* d_desc, uint32_t n, uint64_t total_bytes, int poly_idx, int num_cus,
+                           hipStream_t stream);
+
 // Wavefronts that share one window (1, 2, 4, 8 or 16).
 int crc_choose_group(uint64_t n_windows, uint32_t bpc, int num_cus);
 

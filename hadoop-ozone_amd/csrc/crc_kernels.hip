@@ -427,6 +427,48 @@ __device__ __forceinline__ Win window_of(const CrcLaunch& p, uint64_t g) {
   return w;
 }
 
+// The registers of the two windows a lane group works on (rows A and B of the wavefront), valid in the last
+// lane of each group.  All 64 lanes call together.
+template <int LPW, bool AL>
+__device__ __forceinline__ void subwave_pair(const char* lds, uint32_t lb01, uint32_t lb23, int sl, const Win& wa,
+                                             const Win& wb, uint32_t& x, uint32_t& y) {
+  constexpr uint32_t kStripe = 16u * LPW;
+  constexpr int kLevels = LPW == 4 ? 2 : LPW == 8 ? 3 : LPW == 16 ? 4 : 5;
+  uintptr_t ua = wa.e16 - (uintptr_t)wa.nst * kStripe + 16u * sl;
+  uintptr_t ub = wb.e16 - (uintptr_t)wb.nst * kStripe + 16u * sl;
+  Acc4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+  if (wa.nst) a = AL ? first_unit_aligned(ua, wa.s) : first_unit(ua, wa.s);
+  if (wb.nst) b = AL ? first_unit_aligned(ub, wb.s) : first_unit(ub, wb.s);
+  ua += kStripe;
+  ub += kStripe;
+  uint4 na = make_uint4(0, 0, 0, 0), nb = make_uint4(0, 0, 0, 0);
+  if (1 < wa.nst) na = AL ? ld16(ua) : xor4(ld16(ua), init_spill(ua, wa.s));
+  if (1 < wb.nst) nb = AL ? ld16(ub) : xor4(ld16(ub), init_spill(ub, wb.s));
+  for (uint32_t j = 1; __ballot(j < wa.nst || j < wb.nst) != 0ull; j++) {
+    const uint4 ca = na, cb = nb;
+    ua += kStripe;
+    ub += kStripe;
+    if (j + 1 < wa.nst) na = ld16(ua);
+    if (j + 1 < wb.nst) nb = ld16(ub);
+    if (j < wa.nst) absorb(lds, lb01, lb23, a, ca);
+    if (j < wb.nst) absorb(lds, lb01, lb23, b, cb);
+  }
+  // Fold.  Only the last lane of a group needs its window's register, so level i has work for the lanes
+  // whose low i+1 bits are all ones (they take in the lane 2^i below).  That leaves the lanes below idle:
+  // they advance row B's values in the same instruction stream, and the result moves up by one DPP shift.
+  // Lanes outside that pattern end up with values nobody reads.
+  x = slot_fold(lds, a);
+  y = slot_fold(lds, b);
+#pragma unroll
+  for (int i = 0; i < kLevels; i++) {
+    const bool taker = (sl & ((2 << i) - 1)) == (2 << i) - 1;
+    const uint32_t below = lanes_up(x, i);  // outside the select: every lane must execute the shift
+    const uint32_t t = nib_apply(lds, kOpZ16 + i, taker ? below : y);
+    x ^= t;
+    y ^= lanes_up(t, i);
+  }
+}
+
 template <int LPW, int MODE, bool AL>
 __global__ __launch_bounds__(kThreads) void crc_subwave_kernel(const CrcLaunch p) {
   __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
@@ -452,41 +494,70 @@ __global__ __launch_bounds__(kThreads) void crc_subwave_kernel(const CrcLaunch p
        w0 += (uint64_t)gridDim.x * kWaves * kWinPerWave) {
     const uint64_t ga = w0 + grp, gb = w0 + kWinPerRow + grp;
     const Win wa = window_of<kStripe>(p, ga), wb = window_of<kStripe>(p, gb);
-    uintptr_t ua = wa.e16 - (uintptr_t)wa.nst * kStripe + 16u * sl;
-    uintptr_t ub = wb.e16 - (uintptr_t)wb.nst * kStripe + 16u * sl;
-    Acc4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
-    if (wa.nst) a = AL ? first_unit_aligned(ua, wa.s) : first_unit(ua, wa.s);
-    if (wb.nst) b = AL ? first_unit_aligned(ub, wb.s) : first_unit(ub, wb.s);
-    ua += kStripe;
-    ub += kStripe;
-    uint4 na = make_uint4(0, 0, 0, 0), nb = make_uint4(0, 0, 0, 0);
-    if (1 < wa.nst) na = AL ? ld16(ua) : xor4(ld16(ua), init_spill(ua, wa.s));
-    if (1 < wb.nst) nb = AL ? ld16(ub) : xor4(ld16(ub), init_spill(ub, wb.s));
-    for (uint32_t j = 1; __ballot(j < wa.nst || j < wb.nst) != 0ull; j++) {
-      const uint4 ca = na, cb = nb;
-      ua += kStripe;
-      ub += kStripe;
-      if (j + 1 < wa.nst) na = ld16(ua);
-      if (j + 1 < wb.nst) nb = ld16(ub);
-      if (j < wa.nst) absorb(lds, lb01, lb23, a, ca);
-      if (j < wb.nst) absorb(lds, lb01, lb23, b, cb);
-    }
-    // Fold.  Only the last lane of a group needs its window's register, so level i has work for the lanes
-    // whose low i+1 bits are all ones (they take in the lane 2^i below).  That leaves the lanes below idle:
-    // they advance row B's values in the same instruction stream, and the result moves up by one DPP shift.
-    // Lanes outside that pattern end up with values nobody reads.
-    uint32_t x = slot_fold(lds, a), y = slot_fold(lds, b);
-#pragma unroll
-    for (int i = 0; i < kLevels; i++) {
-      const bool taker = (sl & ((2 << i) - 1)) == (2 << i) - 1;
-      const uint32_t below = lanes_up(x, i);  // outside the select: every lane must execute the shift
-      const uint32_t t = nib_apply(lds, kOpZ16 + i, taker ? below : y);
-      x ^= t;
-      y ^= lanes_up(t, i);
-    }
+    uint32_t x, y;
+    subwave_pair<LPW, AL>(lds, lb01, lb23, sl, wa, wb, x, y);
     if (sl == LPW - 1) {  // the last lane of a group holds its window's register
       if (wa.valid) emit<MODE>(p, ga, wa.chunk, wa.wi, finish_window(x, wa.vec, wa.s, wa.e16, wa.e, poly));
       if (wb.valid) emit<MODE>(p, gb, wb.chunk, wb.wi, finish_window(y, wb.vec, wb.s, wb.e16, wb.e, poly));
+    }
+  }
+}
+
+// Windows given one by one (start, length, where the digest goes): a batch of unrelated small chunks in one
+// launch.  Same work per window as crc_subwave_kernel with the any-alignment geometry.
+template <uint32_t kStripe>
+__device__ __forceinline__ Win window_of_desc(const WindowDesc* desc, uint32_t n, uint64_t g) {
+  Win w{};
+  w.valid = g < n;
+  if (w.valid) {
+    const WindowDesc d = desc[g];
+    w.s = reinterpret_cast<uintptr_t>(d.data);
+    w.e = w.s + d.len;
+    w.e16 = w.e & ~(uintptr_t)15;
+    w.vec = w.e16 >= w.s + 4;
+    if (w.vec) w.nst = (uint32_t)((w.e16 - (w.s & ~(uintptr_t)15) + kStripe - 1) / kStripe);
+  }
+  return w;
+}
+
+__device__ __forceinline__ void store_be(uint8_t* out, uint32_t be) {
+  if ((reinterpret_cast<uintptr_t>(out) & 3) == 0) {
+    *reinterpret_cast<uint32_t*>(out) = be;
+  } else {
+    out[0] = (uint8_t)be; out[1] = (uint8_t)(be >> 8); out[2] = (uint8_t)(be >> 16); out[3] = (uint8_t)(be >> 24);
+  }
+}
+
+template <int LPW>
+__global__ __launch_bounds__(kThreads) void crc_desc_kernel(const WindowDesc* desc, uint32_t n, int poly_idx) {
+  __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
+  constexpr uint32_t kStripe = 16u * LPW;
+  constexpr int kWinPerRow = 64 / LPW;
+  constexpr int kWinPerWave = 2 * kWinPerRow;
+  constexpr int kLevels = LPW == 4 ? 2 : LPW == 8 ? 3 : LPW == 16 ? 4 : 5;
+  constexpr int kMainOp = kOpZ16 + kLevels;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  build_tables(lds, c_basis[poly_idx], kMainOp, tid);
+  __syncthreads();
+
+  const uint32_t lb01 = (uint32_t)(lane & 31) * 4u;
+  const uint32_t lb23 = lb01 + 65536u;
+  const int sl = lane & (LPW - 1);
+  const int grp = lane / LPW;
+  const uint32_t poly = poly_idx ? kPolyCrc32c : kPolyCrc32;
+
+  for (uint64_t w0 = ((uint64_t)blockIdx.x * kWaves + wave) * kWinPerWave; w0 < n;
+       w0 += (uint64_t)gridDim.x * kWaves * kWinPerWave) {
+    const uint64_t ga = w0 + grp, gb = w0 + kWinPerRow + grp;
+    const Win wa = window_of_desc<kStripe>(desc, n, ga), wb = window_of_desc<kStripe>(desc, n, gb);
+    uint32_t x, y;
+    subwave_pair<LPW, false>(lds, lb01, lb23, sl, wa, wb, x, y);
+    if (sl == LPW - 1) {
+      if (wa.valid) store_be(desc[ga].out, finish_window(x, wa.vec, wa.s, wa.e16, wa.e, poly));
+      if (wb.valid) store_be(desc[gb].out, finish_window(y, wb.vec, wb.s, wb.e16, wb.e, poly));
     }
   }
 }
@@ -688,6 +759,26 @@ int crc_choose_lpw(uint64_t n_windows, uint32_t bpc, int num_cus) {
   const int cap = bpc >= 4096 ? 64 : bpc >= 2048 ? 32 : bpc >= 1024 ? 16 : bpc >= 256 ? 8 : 4;
   const int lpw = want < cap ? want : cap;
   return lpw == 64 ? 0 : lpw;
+}
+
+hipError_t crc_launch_desc(const WindowDesc* d_desc, uint32_t n, uint64_t total_bytes, int poly_idx, int num_cus,
+                           hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  // lanes per window as for a uniform batch of the same average window size; never the wavefront-per-window
+  // kernels (0), which have no descriptor form
+  const uint64_t avg = total_bytes / n;
+  int lpw = crc_choose_lpw(n, (uint32_t)(avg > 262144 ? 262144 : (avg ? avg : 1)), num_cus);
+  if (lpw == 0) lpw = 32;
+  const uint64_t per_block = (uint64_t)kWaves * 2 * (64 / lpw);
+  uint64_t nb = (n + per_block - 1) / per_block;
+  if (nb > (uint64_t)num_cus) nb = num_cus;
+  switch (lpw) {
+    case 4: crc_desc_kernel<4><<<(int)nb, kThreads, 0, stream>>>(d_desc, n, poly_idx); break;
+    case 8: crc_desc_kernel<8><<<(int)nb, kThreads, 0, stream>>>(d_desc, n, poly_idx); break;
+    case 16: crc_desc_kernel<16><<<(int)nb, kThreads, 0, stream>>>(d_desc, n, poly_idx); break;
+    default: crc_desc_kernel<32><<<(int)nb, kThreads, 0, stream>>>(d_desc, n, poly_idx); break;
+  }
+  return hipGetLastError();
 }
 
 hipError_t crc_launch(const CrcLaunch& launch, int mode, int group, int num_cus, hipStream_t stream) {

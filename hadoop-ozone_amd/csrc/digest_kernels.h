@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "crc_kernels.h"  // WindowDesc
+
 namespace ozcs {
 
 enum { kAlgoSha256 = 0, kAlgoMd5 = 1 };
@@ -43,5 +45,8 @@ struct DigestJobList {
   int algo;
 };
 hipError_t digest_launch_jobs(const DigestJobList& p, int num_cus, hipStream_t stream);
+
+// SHA-256 / MD5 of n described windows (crc_kernels.h), the list in device memory: one lane per window.
+hipError_t digest_launch_desc(const WindowDesc* d_desc, uint32_t n, int algo, hipStream_t stream);
 
 }  // namespace ozcs

@@ -469,6 +469,28 @@ __global__ __launch_bounds__(kLanes) void digest_jobs_kernel(const DigestJobList
   if (valid) store_digest<H>(out, h);
 }
 
+// Windows given one by one (start, length, where the digest goes): any number of unrelated small chunks in one
+// launch, the list in device memory.
+template <class H>
+__global__ __launch_bounds__(kLanes) void digest_desc_kernel(const WindowDesc* desc, uint32_t n) {
+  __shared__ __attribute__((aligned(16))) char stage[kLanes * row_bytes<H::kStepBlocks>()];
+  const int lane = threadIdx.x;
+  const uint32_t g = blockIdx.x * kLanes + lane;
+  const bool valid = g < n;
+  uint64_t start = 0;
+  uint32_t len = 0;
+  uint8_t* out = nullptr;
+  if (valid) {
+    const WindowDesc d = desc[g];
+    start = reinterpret_cast<uintptr_t>(d.data);
+    len = d.len;
+    out = d.out;
+  }
+  uint32_t h[H::kWords];
+  digest_core<H>(stage, lane, valid, start, len, h);
+  if (valid) store_digest<H>(out, h);
+}
+
 // The split SHA-256 forms of the two kernels above (workgroup = 256 threads = 128 windows).
 template <int MODE>
 __global__ __launch_bounds__(kSplitThreads) void sha256_split_windows_kernel(const DigestLaunch p) {
@@ -564,6 +586,14 @@ hipError_t digest_launch(const DigestLaunch& p, int mode, int num_cus, hipStream
     if (mode == kModeCompute) digest_windows_kernel<Md5, kModeCompute><<<grid, block, 0, stream>>>(p);
     else digest_windows_kernel<Md5, kModeVerify><<<grid, block, 0, stream>>>(p);
   }
+  return hipGetLastError();
+}
+
+hipError_t digest_launch_desc(const WindowDesc* d_desc, uint32_t n, int algo, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  const dim3 grid((n + kLanes - 1) / kLanes), block(kLanes);
+  if (algo == kAlgoSha256) digest_desc_kernel<Sha256><<<grid, block, 0, stream>>>(d_desc, n);
+  else digest_desc_kernel<Md5><<<grid, block, 0, stream>>>(d_desc, n);
   return hipGetLastError();
 }
 

@@ -101,6 +101,8 @@ static void destroy_ctx(HostCtx* c) {
   if (c->d_data) (void)hipFree(c->d_data);
   if (c->d_sums) (void)hipFree(c->d_sums);
   if (c->d_aux) (void)hipFree(c->d_aux);
+  if (c->h_stage) (void)hipHostFree(c->h_stage);
+  if (c->h_sums) (void)hipHostFree(c->h_sums);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -118,6 +120,24 @@ int ctx_reserve(void** buf, size_t* cap, size_t need) {
     want = need;
   }
   if (e != hipSuccess) return fail(OZCS_ENOMEM, "hipMalloc(%zu): %s", need, hipGetErrorString(e));
+  *cap = want;
+  return OZCS_OK;
+}
+
+// Grow-only pinned host buffer.
+static int host_reserve(void** buf, size_t* cap, size_t need) {
+  if (need <= *cap) return OZCS_OK;
+  if (*buf) (void)hipHostFree(*buf);
+  *buf = nullptr;
+  *cap = 0;
+  size_t want = need + need / 4;
+  want = (want + 4095) & ~(size_t)4095;
+  hipError_t e = hipHostMalloc(buf, want, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    e = hipHostMalloc(buf, need, hipHostMallocDefault);
+    want = need;
+  }
+  if (e != hipSuccess) return fail(OZCS_ENOMEM, "hipHostMalloc(%zu): %s", need, hipGetErrorString(e));
   *cap = want;
   return OZCS_OK;
 }
@@ -218,11 +238,23 @@ static int compute_host_on(int device, int type, uint32_t bpc, const void* data,
   return rc;
 }
 
-// One device's share [lo, hi) of a chunk list: the chunks are staged into one device buffer in groups of
-// at most kBatchStageBytes, CRC chunks are launched one by one (each launch already fills the chip for a
-// 4 MiB chunk), SHA-256 / MD5 chunks go through the job-list kernel so that their few windows per chunk
-// add up to full wavefronts.  Per-chunk status and n_sums are filled in.
+// One device's share [lo, hi) of a chunk list, in groups of at most kBatchStageBytes of data.
+//
+// A copy call and a launch per chunk cost some 25 us per chunk whatever its size, and a copy from pageable
+// memory runs at half the link's rate.  So chunks of up to kStagedChunkBytes are gathered into one pinned
+// staging buffer, which is copied to the device in 8 MiB pieces while the gathering goes on; and the small
+// ones among them (at most kSmallChunkBytes and kSmallChunkWindows windows: small keys, the tail chunks of
+// files) get a descriptor per window (start, length, where the digest goes) and ONE launch per checksum type
+// works through the descriptors.  The others keep a launch of their own (a 4 MiB chunk occupies the memory
+// pipeline by itself); large SHA-256 / MD5 chunks go through the job-list kernel so that their few windows per
+// chunk add up to full wavefronts.  Digests come back in one copy when they fit the pinned return buffer.
+// Per-chunk status and n_sums are filled in.
 constexpr uint64_t kBatchStageBytes = 512ull << 20;
+constexpr uint64_t kStagedChunkBytes = 8ull << 20;
+constexpr uint64_t kSmallChunkBytes = 1ull << 20;
+constexpr uint64_t kSmallChunkWindows = 64;
+constexpr uint64_t kStagePiece = 8ull << 20;
+constexpr uint64_t kPinnedSumsMax = 32ull << 20;
 
 static void batch_on_device(int device, ozcs_chunk* chunks, uint32_t lo, uint32_t hi) {
   auto fail_all = [&](uint32_t a, uint32_t b, int code) {
@@ -234,12 +266,13 @@ static void batch_on_device(int device, ozcs_chunk* chunks, uint32_t lo, uint32_
   if (!dg.ok()) return fail_all(lo, hi, fail(OZCS_ENODEV, "cannot select device %d", device));
   HostCtx* c = acquire_ctx(device);
   if (!c) return fail_all(lo, hi, fail(OZCS_EHIP, "cannot create a stream on device %d", device));
-  struct Item { uint32_t idx; uint64_t data_off, sums_off, n; size_t ds; };
+  struct Item { uint32_t idx; uint64_t data_off, sums_off, n; size_t ds; bool staged, small; };
+  const int kTypes[4] = {OZCS_CRC32, OZCS_CRC32C, OZCS_SHA256, OZCS_MD5};
   uint32_t i = lo;
   while (i < hi) {
     // ---- pick a group that fits the staging budget, validating as we go ----
     std::vector<Item> items;
-    uint64_t data_bytes = 0, sums_bytes = 0;
+    uint64_t group_bytes = 0;
     uint32_t j = i;
     for (; j < hi; j++) {
       ozcs_chunk& ch = chunks[j];
@@ -250,20 +283,91 @@ static void batch_on_device(int device, ozcs_chunk* chunks, uint32_t lo, uint32_
       const uint64_t n = ozcs_num_checksums(ch.len, ch.bpc);
       if (!ch.data || !ch.sums) { ch.status = fail(OZCS_EINVAL, "null pointer in chunk %u", j); continue; }
       if (ch.sums_cap < n * ds) { ch.status = fail(OZCS_EINVAL, "sums_cap too small in chunk %u", j); continue; }
-      if (!items.empty() && data_bytes + ch.len > kBatchStageBytes) break;
-      items.push_back(Item{j, data_bytes, sums_bytes, n, ds});
-      data_bytes += (ch.len + 255) & ~(uint64_t)255;
-      sums_bytes += (n * ds + 255) & ~(uint64_t)255;
+      if (!items.empty() && group_bytes + ch.len > kBatchStageBytes) break;
+      items.push_back(Item{j, 0, 0, n, ds, ch.len <= kStagedChunkBytes, ch.len <= kSmallChunkBytes && n <= kSmallChunkWindows});
+      group_bytes += (ch.len + 255) & ~(uint64_t)255;
     }
     const uint32_t group_end = j;
     if (!items.empty()) {
+      // ---- layout: staged chunks first (one contiguous region), then the others ----
+      uint64_t data_bytes = 0, sums_bytes = 0, n_desc = 0, staged_bytes = 0;
+      for (int pass = 0; pass < 2; pass++) {
+        for (Item& it : items) {
+          if (it.staged != (pass == 0)) continue;
+          it.data_off = data_bytes;
+          data_bytes += (chunks[it.idx].len + 255) & ~(uint64_t)255;
+          if (it.small) n_desc += it.n;
+        }
+        if (pass == 0) staged_bytes = data_bytes;
+      }
+      for (Item& it : items) {
+        it.sums_off = sums_bytes;
+        sums_bytes += it.small ? ((it.n * it.ds + 31) & ~(uint64_t)31) : ((it.n * it.ds + 255) & ~(uint64_t)255);
+      }
+      const bool pinned_sums = sums_bytes <= kPinnedSumsMax;
       int rc = ctx_reserve(&c->d_data, &c->data_cap, data_bytes);
       if (rc == OZCS_OK) rc = ctx_reserve(&c->d_sums, &c->sums_cap, sums_bytes);
+      if (rc == OZCS_OK && n_desc) rc = ctx_reserve(&c->d_aux, &c->aux_cap, n_desc * sizeof(WindowDesc));
+      if (rc == OZCS_OK && staged_bytes) rc = host_reserve(&c->h_stage, &c->h_stage_cap, staged_bytes + n_desc * sizeof(WindowDesc));
+      if (rc == OZCS_OK && pinned_sums) rc = host_reserve(&c->h_sums, &c->h_sums_cap, sums_bytes);
       hipError_t e = hipSuccess;
       uint8_t* dd = static_cast<uint8_t*>(c->d_data);
       uint8_t* dsums = static_cast<uint8_t*>(c->d_sums);
+      if (rc == OZCS_OK && staged_bytes) {
+        // ---- gather the staged chunks; each finished piece starts its copy while the next is gathered ----
+        uint8_t* hs = static_cast<uint8_t*>(c->h_stage);
+        uint64_t sent = 0;
+        for (const Item& it : items) {
+          if (!it.staged) continue;
+          const ozcs_chunk& ch = chunks[it.idx];
+          memcpy(hs + it.data_off, ch.data, ch.len);
+          const uint64_t end = it.data_off + ((ch.len + 255) & ~(uint64_t)255);
+          if (end - sent >= kStagePiece && e == hipSuccess) {
+            e = hipMemcpyAsync(dd + sent, hs + sent, end - sent, hipMemcpyHostToDevice, c->stream);
+            sent = end;
+          }
+        }
+        if (staged_bytes > sent && e == hipSuccess)
+          e = hipMemcpyAsync(dd + sent, hs + sent, staged_bytes - sent, hipMemcpyHostToDevice, c->stream);
+      }
+      if (rc == OZCS_OK && n_desc) {
+        // ---- descriptors of the small chunks' windows, grouped by checksum type ----
+        WindowDesc* hd = reinterpret_cast<WindowDesc*>(static_cast<uint8_t*>(c->h_stage) + staged_bytes);
+        WindowDesc* ddsc = static_cast<WindowDesc*>(c->d_aux);
+        uint64_t first[5] = {0, 0, 0, 0, 0}, bytes[4] = {0, 0, 0, 0};
+        uint64_t k = 0;
+        for (int t = 0; t < 4; t++) {
+          first[t] = k;
+          for (const Item& it : items) {
+            const ozcs_chunk& ch = chunks[it.idx];
+            if (!it.small || ch.type != kTypes[t]) continue;
+            for (uint64_t w = 0; w < it.n; w++) {
+              const uint64_t off = w * ch.bpc;
+              hd[k].data = dd + it.data_off + off;
+              hd[k].out = dsums + it.sums_off + w * it.ds;
+              hd[k].len = (uint32_t)(ch.len - off < ch.bpc ? ch.len - off : ch.bpc);
+              hd[k].reserved = 0;
+              k++;
+            }
+            bytes[t] += ch.len;
+          }
+        }
+        first[4] = k;
+        if (e == hipSuccess)
+          e = hipMemcpyAsync(ddsc, hd, n_desc * sizeof(WindowDesc), hipMemcpyHostToDevice, c->stream);
+        for (int t = 0; t < 4 && e == hipSuccess; t++) {
+          const uint64_t nw = first[t + 1] - first[t];
+          if (!nw) continue;
+          if (t < 2) e = crc_launch_desc(ddsc + first[t], (uint32_t)nw, bytes[t], t, dev->num_cus, c->stream);
+          else e = digest_launch_desc(ddsc + first[t], (uint32_t)nw, t == 2 ? kAlgoSha256 : kAlgoMd5, c->stream);
+          s_launches.fetch_add(1, std::memory_order_relaxed);
+          s_windows.fetch_add(nw, std::memory_order_relaxed);
+          s_bytes.fetch_add(bytes[t], std::memory_order_relaxed);
+        }
+      }
+      // ---- the other chunks: a copy each if not staged, digests through the job list, CRC one launch per chunk ----
       for (const Item& it : items)
-        if (rc == OZCS_OK && e == hipSuccess)
+        if (!it.staged && rc == OZCS_OK && e == hipSuccess)
           e = hipMemcpyAsync(dd + it.data_off, chunks[it.idx].data, chunks[it.idx].len, hipMemcpyHostToDevice, c->stream);
       for (int algo = 0; algo < 2 && rc == OZCS_OK && e == hipSuccess; algo++) {
         const int type = algo == kAlgoSha256 ? OZCS_SHA256 : OZCS_MD5;
@@ -280,7 +384,7 @@ static void batch_on_device(int device, ozcs_chunk* chunks, uint32_t lo, uint32_
         };
         for (const Item& it : items) {
           const ozcs_chunk& ch = chunks[it.idx];
-          if (ch.type != type) continue;
+          if (it.small || ch.type != type) continue;
           if (jl.n_jobs == (uint32_t)kMaxDigestJobs || (uint64_t)jl.n_windows + it.n > 0x7fffffffull) launch();
           DigestJob& job = jl.jobs[jl.n_jobs++];
           job.data = dd + it.data_off;
@@ -295,22 +399,31 @@ static void batch_on_device(int device, ozcs_chunk* chunks, uint32_t lo, uint32_
       }
       for (const Item& it : items) {
         const ozcs_chunk& ch = chunks[it.idx];
-        if (ch.type != OZCS_CRC32 && ch.type != OZCS_CRC32C) continue;
+        if (it.small || (ch.type != OZCS_CRC32 && ch.type != OZCS_CRC32C)) continue;
         if (rc == OZCS_OK && e == hipSuccess)
           rc = launch_windows(*dev, ch.type, ch.bpc, dd + it.data_off, ch.len, 1, ch.len, kModeCompute,
                               dsums + it.sums_off, nullptr, 0, 0, 0, nullptr, c->stream);
       }
-      for (const Item& it : items)
-        if (rc == OZCS_OK && e == hipSuccess)
-          e = hipMemcpyAsync(chunks[it.idx].sums, dsums + it.sums_off, it.n * it.ds, hipMemcpyDeviceToHost, c->stream);
+      // ---- digests back: one copy into pinned memory and a scatter, or a copy per chunk ----
+      if (rc == OZCS_OK && e == hipSuccess) {
+        if (pinned_sums) {
+          e = hipMemcpyAsync(c->h_sums, dsums, sums_bytes, hipMemcpyDeviceToHost, c->stream);
+        } else {
+          for (const Item& it : items)
+            if (e == hipSuccess)
+              e = hipMemcpyAsync(chunks[it.idx].sums, dsums + it.sums_off, it.n * it.ds, hipMemcpyDeviceToHost, c->stream);
+        }
+      }
       const hipError_t es = hipStreamSynchronize(c->stream);
       if (rc == OZCS_OK && e != hipSuccess) rc = fail_hip(e, "batch enqueue");
       if (rc == OZCS_OK && es != hipSuccess) rc = fail_hip(es, "hipStreamSynchronize");
       for (const Item& it : items) {
-        chunks[it.idx].status = rc;
-        chunks[it.idx].n_sums = rc == OZCS_OK ? it.n : 0;
+        ozcs_chunk& ch = chunks[it.idx];
+        ch.status = rc;
+        ch.n_sums = rc == OZCS_OK ? it.n : 0;
         if (rc == OZCS_OK) {
-          s_h2d.fetch_add(chunks[it.idx].len, std::memory_order_relaxed);
+          if (pinned_sums) memcpy(ch.sums, static_cast<const uint8_t*>(c->h_sums) + it.sums_off, it.n * it.ds);
+          s_h2d.fetch_add(ch.len, std::memory_order_relaxed);
           s_d2h.fetch_add(it.n * it.ds, std::memory_order_relaxed);
         }
       }

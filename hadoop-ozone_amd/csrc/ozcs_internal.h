@@ -25,6 +25,11 @@ struct HostCtx {
   size_t sums_cap = 0;
   void* d_aux = nullptr;
   size_t aux_cap = 0;
+  // pinned host staging of the batched call (small chunks and window descriptors; digests on the way back)
+  void* h_stage = nullptr;
+  size_t h_stage_cap = 0;
+  void* h_sums = nullptr;
+  size_t h_sums_cap = 0;
 };
 
 struct Global {
