@@ -249,12 +249,14 @@ static int compute_host_on(int device, int type, uint32_t bpc, const void* data,
 // pipeline by itself); large SHA-256 / MD5 chunks go through the job-list kernel so that their few windows per
 // chunk add up to full wavefronts.  Digests come back in one copy when they fit the pinned return buffer.
 // Per-chunk status and n_sums are filled in.
-constexpr uint64_t kBatchStageBytes = 512ull << 20;
+constexpr uint64_t kBatchStageBytes = 256ull << 20;  // also the most pinned memory one in-flight batch call holds
 constexpr uint64_t kStagedChunkBytes = 8ull << 20;
 constexpr uint64_t kSmallChunkBytes = 1ull << 20;
 constexpr uint64_t kSmallChunkWindows = 64;
 constexpr uint64_t kStagePiece = 8ull << 20;
 constexpr uint64_t kPinnedSumsMax = 32ull << 20;
+constexpr size_t kGatherThreads = 4;
+constexpr uint64_t kGatherBytesPerThread = 32ull << 20;  // below 64 MiB of staged data one thread gathers
 
 static void batch_on_device(int device, ozcs_chunk* chunks, uint32_t lo, uint32_t hi) {
   auto fail_all = [&](uint32_t a, uint32_t b, int code) {
@@ -314,21 +316,53 @@ static void batch_on_device(int device, ozcs_chunk* chunks, uint32_t lo, uint32_
       uint8_t* dd = static_cast<uint8_t*>(c->d_data);
       uint8_t* dsums = static_cast<uint8_t*>(c->d_sums);
       if (rc == OZCS_OK && staged_bytes) {
-        // ---- gather the staged chunks; each finished piece starts its copy while the next is gathered ----
+        // ---- gather the staged chunks; each finished piece starts its copy while the next is gathered.
+        // One thread's memcpy feeds about half of what the link takes, so large gathers are shared by up to
+        // kGatherThreads threads, each with a contiguous run of the staged items (copies of different
+        // pieces may be queued in any order: the kernels come after all of them on the same stream). ----
         uint8_t* hs = static_cast<uint8_t*>(c->h_stage);
-        uint64_t sent = 0;
-        for (const Item& it : items) {
-          if (!it.staged) continue;
-          const ozcs_chunk& ch = chunks[it.idx];
-          memcpy(hs + it.data_off, ch.data, ch.len);
-          const uint64_t end = it.data_off + ((ch.len + 255) & ~(uint64_t)255);
-          if (end - sent >= kStagePiece && e == hipSuccess) {
-            e = hipMemcpyAsync(dd + sent, hs + sent, end - sent, hipMemcpyHostToDevice, c->stream);
-            sent = end;
+        std::vector<const Item*> staged;
+        for (const Item& it : items)
+          if (it.staged) staged.push_back(&it);
+        auto gather = [&](size_t a, size_t b, hipError_t* err) {
+          DeviceGuard tg(device);
+          uint64_t sent = staged[a]->data_off, end = sent;
+          for (size_t q = a; q < b; q++) {
+            const ozcs_chunk& ch = chunks[staged[q]->idx];
+            memcpy(hs + staged[q]->data_off, ch.data, ch.len);
+            end = staged[q]->data_off + ((ch.len + 255) & ~(uint64_t)255);
+            if (end - sent >= kStagePiece && *err == hipSuccess) {
+              *err = hipMemcpyAsync(dd + sent, hs + sent, end - sent, hipMemcpyHostToDevice, c->stream);
+              sent = end;
+            }
           }
+          if (end > sent && *err == hipSuccess)
+            *err = hipMemcpyAsync(dd + sent, hs + sent, end - sent, hipMemcpyHostToDevice, c->stream);
+        };
+        size_t nthreads = (size_t)(staged_bytes / kGatherBytesPerThread);
+        if (nthreads > kGatherThreads) nthreads = kGatherThreads;
+        if (nthreads > staged.size()) nthreads = staged.size();
+        if (nthreads <= 1) {
+          gather(0, staged.size(), &e);
+        } else {
+          // split by bytes, not by item count
+          std::vector<size_t> cut(nthreads + 1, staged.size());
+          cut[0] = 0;
+          size_t q = 0;
+          for (size_t t = 1; t < nthreads; t++) {
+            const uint64_t target = staged_bytes * t / nthreads;
+            while (q < staged.size() && staged[q]->data_off < target) q++;
+            cut[t] = q;
+          }
+          std::vector<hipError_t> errs(nthreads, hipSuccess);
+          std::vector<std::thread> th;
+          for (size_t t = 1; t < nthreads; t++)
+            if (cut[t] < cut[t + 1]) th.emplace_back(gather, cut[t], cut[t + 1], &errs[t]);
+          if (cut[0] < cut[1]) gather(cut[0], cut[1], &errs[0]);
+          for (auto& t : th) t.join();
+          for (hipError_t x : errs)
+            if (x != hipSuccess && e == hipSuccess) e = x;
         }
-        if (staged_bytes > sent && e == hipSuccess)
-          e = hipMemcpyAsync(dd + sent, hs + sent, staged_bytes - sent, hipMemcpyHostToDevice, c->stream);
       }
       if (rc == OZCS_OK && n_desc) {
         // ---- descriptors of the small chunks' windows, grouped by checksum type ----
