@@ -249,7 +249,7 @@ static int compute_host_on(int device, int type, uint32_t bpc, const void* data,
 // pipeline by itself); large SHA-256 / MD5 chunks go through the job-list kernel so that their few windows per
 // chunk add up to full wavefronts.  Digests come back in one copy when they fit the pinned return buffer.
 // Per-chunk status and n_sums are filled in.
-constexpr uint64_t kBatchStageBytes = 256ull << 20;  // also the most pinned memory one in-flight batch call holds
+constexpr uint64_t kBatchStageBytes = 512ull << 20;  // also the most pinned memory one in-flight batch call holds
 constexpr uint64_t kStagedChunkBytes = 8ull << 20;
 constexpr uint64_t kSmallChunkBytes = 1ull << 20;
 constexpr uint64_t kSmallChunkWindows = 64;
