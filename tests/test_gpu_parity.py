@@ -729,3 +729,12 @@ def test_full_size_properties_other_configurations(gpu):
     q = nbytes // 4
     sh2 = dev_compute(gpu, oracle.SHA256, MIB, a, 8 * MIB, q // (8 * MIB), 8 * MIB)   # 8 MiB chunks: same windows
     assert sh2 == sh[: (q // MIB) * 32]
+
+
+def test_large_host_buffer_takes_the_piecewise_path(gpu):
+    # ozcs_compute on 32 MiB or more is cut into pieces of whole windows and gathered through pinned memory
+    torch, native, L = gpu
+    d = oracle.splitmix64(8080, 72 * MIB + 12345)
+    for t, bpc in ((oracle.CRC32, MIB), (oracle.CRC32C, 1000003), (oracle.CRC32, 3 * MIB + 16), (oracle.MD5, 65536),
+                   (oracle.SHA256, 700001), (oracle.CRC32C, 16 * MIB)):
+        assert native.compute(t, bpc, d) == oracle.compute(t, bpc, d), (t, bpc)
