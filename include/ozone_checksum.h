@@ -116,7 +116,11 @@ typedef struct ozcs_chunk {
 
 /* The loop of BlockOutputStream.writeChunkToContainer (BlockOutputStream.java:645-656) over many
  * chunks at once.  Chunks are sharded contiguously over the initialised devices (chunk list, not
- * windows); there is no inter-device traffic.  Returns the first non-OK per-chunk status, or OZCS_OK. */
+ * windows); there is no inter-device traffic.  Chunks of any sizes and types may be mixed: small ones (small
+ * keys, tail chunks) are gathered and served by one kernel launch per checksum type, so the cost per small
+ * chunk is well under a microsecond rather than a copy and a launch each.  A call in flight holds up to
+ * 512 MiB of pinned host memory and as much device memory (kept for the next call of the same thread pool
+ * slot, released by ozcs_shutdown).  Returns the first non-OK per-chunk status, or OZCS_OK. */
 OZCS_API int ozcs_compute_batch(ozcs_chunk* chunks, uint32_t n_chunks);
 
 typedef struct ozcs_vchunk {
