@@ -468,6 +468,28 @@ static void batch_on_device(int device, ozcs_chunk* chunks, uint32_t lo, uint32_
   release_ctx(c);
 }
 
+// Appends one host buffer to a chunk list: as one chunk, or -- from kSplitCallBytes on -- as pieces of whole
+// windows, so that the batched path's pinned, threaded gather carries it instead of one copy from pageable
+// memory (40 GB/s and more against under 30).  `sums` receives the digests back to back either way.
+static void append_pieces(std::vector<ozcs_chunk>& out, int type, uint32_t bpc, const void* data, uint64_t len,
+                          void* sums, size_t ds) {
+  uint64_t piece = len, wpp = 0;
+  if (len >= kSplitCallBytes && bpc <= kStagedChunkBytes) {
+    wpp = kStagedChunkBytes / bpc;
+    piece = wpp * bpc;
+  }
+  for (uint64_t off = 0, w = 0; off < len; off += piece, w += wpp) {
+    ozcs_chunk p{};
+    p.data = static_cast<const uint8_t*>(data) + off;
+    p.len = len - off < piece ? len - off : piece;
+    p.sums = static_cast<uint8_t*>(sums) + w * ds;
+    p.sums_cap = ozcs_num_checksums(p.len, bpc) * ds;
+    p.bpc = bpc;
+    p.type = type;
+    out.push_back(p);
+  }
+}
+
 }  // namespace ozcs
 
 using namespace ozcs;
@@ -610,20 +632,8 @@ int ozcs_compute(int type, uint32_t bpc, const void* data, uint64_t len, void* s
   if ((rc = ensure_init()) != OZCS_OK) return rc;
   s_calls.fetch_add(1, std::memory_order_relaxed);
   if (len >= kSplitCallBytes && bpc <= kStagedChunkBytes) {
-    // A large buffer takes the batched path as a list of pieces of whole windows: its pinned, threaded
-    // gather moves 40 GB/s or more where one copy from pageable memory moves under 30.
-    const uint64_t wpp = kStagedChunkBytes / bpc, piece = wpp * bpc;  // windows and bytes per piece
     std::vector<ozcs_chunk> parts;
-    for (uint64_t off = 0, w = 0; off < len; off += piece, w += wpp) {
-      ozcs_chunk p{};
-      p.data = static_cast<const uint8_t*>(data) + off;
-      p.len = len - off < piece ? len - off : piece;
-      p.sums = static_cast<uint8_t*>(sums_out) + w * ds;
-      p.sums_cap = ozcs_num_checksums(p.len, bpc) * ds;
-      p.bpc = bpc;
-      p.type = type;
-      parts.push_back(p);
-    }
+    append_pieces(parts, type, bpc, data, len, sums_out, ds);
     batch_on_device(pick_device(), parts.data(), 0, (uint32_t)parts.size());
     for (const ozcs_chunk& p : parts)
       if (p.status != OZCS_OK) return p.status;
@@ -647,6 +657,19 @@ int ozcs_verify(int type, uint32_t bpc, const void* data, uint64_t len, const vo
   if (n == 0) return fail(OZCS_EEMPTY, "Computed checksumData has no checksums");          // ChecksumData.java:126-129
   if (!data || !expected) return fail(OZCS_EINVAL, "null pointer");
   if ((rc = ensure_init()) != OZCS_OK) return rc;
+  if (len >= kSplitCallBytes && bpc <= kStagedChunkBytes) {  // large buffer: the batched path moves it faster
+    ozcs_vchunk vc{};
+    vc.data = data;
+    vc.len = len;
+    vc.expected = expected;
+    vc.n_expected = n_expected;
+    vc.start_index = start_index;
+    vc.bpc = bpc;
+    vc.type = type;
+    (void)ozcs_verify_batch(&vc, 1);
+    if (vc.status == OZCS_OK && first_mismatch) *first_mismatch = vc.first_mismatch;
+    return vc.status;
+  }
   const int device = pick_device();
   const DeviceInfo* dev = find_device(device);
   if (!dev) return fail(OZCS_ENODEV, "device %d is not initialised", device);
@@ -728,9 +751,9 @@ int ozcs_verify_batch(ozcs_vchunk* v, uint32_t n_chunks) {
   // Hash everything that needs hashing through the batched compute path into scratch digests, then compare
   // on the host: digests are a few bytes per window, the hashing is the work.
   std::vector<ozcs_chunk> jobs;
-  std::vector<uint32_t> owner;
+  struct Owner { uint32_t idx; size_t first_job, end_job; uint64_t n; };
+  std::vector<Owner> owners;
   std::vector<std::vector<uint8_t>> sums;
-  jobs.reserve(n_chunks);
   for (uint32_t i = 0; i < n_chunks; i++) {
     ozcs_vchunk& c = v[i];
     c.first_mismatch = -1;
@@ -740,28 +763,24 @@ int ozcs_verify_batch(ozcs_vchunk* v, uint32_t n_chunks) {
     if (c.n_expected == 0) { c.status = fail(OZCS_EEMPTY, "Original checksumData has no checksums"); continue; }
     if (n == 0) { c.status = fail(OZCS_EEMPTY, "Computed checksumData has no checksums"); continue; }
     if (!c.data || !c.expected) { c.status = fail(OZCS_EINVAL, "null pointer in chunk %u", i); continue; }
-    sums.emplace_back((size_t)(n * ozcs_digest_size(c.type)));
-    ozcs_chunk j{};
-    j.data = c.data;
-    j.len = c.len;
-    j.sums = sums.back().data();
-    j.sums_cap = sums.back().size();
-    j.bpc = c.bpc;
-    j.type = c.type;
-    jobs.push_back(j);
-    owner.push_back(i);
+    const size_t ds = ozcs_digest_size(c.type);
+    sums.emplace_back((size_t)(n * ds));
+    const size_t first_job = jobs.size();
+    append_pieces(jobs, c.type, c.bpc, c.data, c.len, sums.back().data(), ds);
+    owners.push_back(Owner{i, first_job, jobs.size(), n});
   }
   if (!jobs.empty()) (void)ozcs_compute_batch(jobs.data(), (uint32_t)jobs.size());
-  for (size_t k = 0; k < jobs.size(); k++) {
-    ozcs_vchunk& c = v[owner[k]];
-    if (jobs[k].status != OZCS_OK) { c.status = jobs[k].status; continue; }
+  for (size_t k = 0; k < owners.size(); k++) {
+    ozcs_vchunk& c = v[owners[k].idx];
+    for (size_t j = owners[k].first_job; j < owners[k].end_job && c.status == OZCS_OK; j++) c.status = jobs[j].status;
+    if (c.status != OZCS_OK) continue;
     const size_t ds = ozcs_digest_size(c.type);
     const uint8_t* ex = static_cast<const uint8_t*>(c.expected);
     const uint8_t* got = sums[k].data();
-    for (uint64_t i = 0; i < jobs[k].n_sums; i++) {  // ChecksumData.java:135-141
+    for (uint64_t i = 0; i < owners[k].n; i++) {  // ChecksumData.java:135-141
       if (c.start_index + i >= c.n_expected) {
         c.status = fail(OZCS_ERANGE, "Computed checksum has %llu number of checksums. Original checksum has %llu number "
-                        "of checksums starting from index %llu", (unsigned long long)jobs[k].n_sums,
+                        "of checksums starting from index %llu", (unsigned long long)owners[k].n,
                         (unsigned long long)(c.n_expected > c.start_index ? c.n_expected - c.start_index : 0),
                         (unsigned long long)c.start_index);
         break;

@@ -738,3 +738,21 @@ def test_large_host_buffer_takes_the_piecewise_path(gpu):
     for t, bpc in ((oracle.CRC32, MIB), (oracle.CRC32C, 1000003), (oracle.CRC32, 3 * MIB + 16), (oracle.MD5, 65536),
                    (oracle.SHA256, 700001), (oracle.CRC32C, 16 * MIB)):
         assert native.compute(t, bpc, d) == oracle.compute(t, bpc, d), (t, bpc)
+
+
+def test_large_host_buffer_verify(gpu):
+    # ozcs_verify on 32 MiB or more goes through the batched path; outcomes as for small buffers
+    torch, native, L = gpu
+    d = oracle.splitmix64(9090, 40 * MIB + 77)
+    for t, bpc in ((oracle.CRC32, MIB), (oracle.CRC32C, 1000003), (oracle.MD5, 262144)):
+        stored = oracle.compute(t, bpc, d)
+        ds = native.DIGEST_SIZE[t]
+        n = len(stored) // ds
+        assert native.verify(t, bpc, d, stored, 0) == (native.OK, -1)
+        bad = d.copy()
+        bad[17 * MIB + 5] ^= 2
+        assert native.verify(t, bpc, bad, stored, 0) == (native.OK, (17 * MIB + 5) // bpc)
+        assert native.verify(t, bpc, d, stored[: (n - 3) * ds], 0)[0] == native.ERANGE
+        assert native.verify(t, bpc, d, b"", 0)[0] == native.EEMPTY
+        assert native.verify(t, bpc, d[5 * bpc:], stored, 5) == (native.OK, -1)
+        assert oracle.verify(t, bpc, bad, stored, 0) == (1, (17 * MIB + 5) // bpc)
