@@ -124,6 +124,21 @@ int ctx_reserve(void** buf, size_t* cap, size_t need) {
   return OZCS_OK;
 }
 
+// Presets the per-chunk verdict words to "no mismatch" (all ones).  A kernel rather than hipMemsetAsync: under
+// stream capture the runtime's memset node left other values in the words (seen on ROCm 7.2), and a kernel
+// is what the rest of the call enqueues anyway.
+__global__ void preset_verdicts_kernel(unsigned long long* v, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = ~0ull;
+}
+static hipError_t preset_verdicts(void* v, uint64_t n, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  const uint64_t blocks = (n + 255) / 256;
+  if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+  preset_verdicts_kernel<<<dim3((unsigned)blocks), dim3(256), 0, stream>>>(static_cast<unsigned long long*>(v), n);
+  return hipGetLastError();
+}
+
 // Grow-only pinned host buffer.
 static int host_reserve(void** buf, size_t* cap, size_t need) {
   if (need <= *cap) return OZCS_OK;
@@ -608,8 +623,8 @@ int ozcs_verify_device(int device, int type, uint32_t bpc, const void* d_data, u
   DeviceGuard dg(device);
   if (!dg.ok()) return fail(OZCS_ENODEV, "cannot select device %d", device);
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-  hipError_t e = hipMemsetAsync(d_first_mismatch, 0xFF, n_chunks * sizeof(int64_t), stream);  // -1 = no mismatch
-  if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync");
+  hipError_t e = preset_verdicts(d_first_mismatch, n_chunks, stream);  // -1 = no mismatch
+  if (e != hipSuccess) return fail_hip(e, "verdict preset");
   if (type == OZCS_NONE || chunk_len == 0) return OZCS_OK;  // Checksum.java:241-244
   if (!d_data || !d_expected) return fail(OZCS_EINVAL, "null device pointer");
   if (n_chunks > 1 && chunk_stride < chunk_len) return fail(OZCS_EINVAL, "chunk_stride < chunk_len");
@@ -692,7 +707,7 @@ int ozcs_verify(int type, uint32_t bpc, const void* data, uint64_t len, const vo
     if (e == hipSuccess && ship)
       e = hipMemcpyAsync(c->d_sums, static_cast<const uint8_t*>(expected) + first * ds, ship * ds,
                          hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(c->d_aux, 0xFF, sizeof(int64_t), c->stream);
+    if (e == hipSuccess) e = preset_verdicts(c->d_aux, 1, c->stream);
     if (e != hipSuccess) rc = fail_hip(e, "hipMemcpyAsync H2D");
   }
   if (rc == OZCS_OK)

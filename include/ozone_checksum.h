@@ -145,7 +145,8 @@ OZCS_API int ozcs_verify_batch(ozcs_vchunk* chunks, uint32_t n_chunks);
 
 /* ---- device-resident: pointers are device memory on `device`, work is queued on hip_stream ----
  * (hip_stream is a hipStream_t passed as void*; NULL = the default stream.)  No implicit
- * synchronisation: results are valid once the stream reaches the end of the call's work. */
+ * synchronisation: results are valid once the stream reaches the end of the call's work.  These calls
+ * allocate nothing and enqueue kernels only, so they may be issued on a stream under HIP graph capture. */
 
 /* n_chunks chunks of chunk_len bytes, chunk c at d_data + c*chunk_stride, each cut into windows from
  * its own offset 0.  Digests of chunk c start at d_sums + c * ceil(chunk_len/bpc) * digest_size. */

@@ -756,3 +756,34 @@ def test_large_host_buffer_verify(gpu):
         assert native.verify(t, bpc, d, b"", 0)[0] == native.EEMPTY
         assert native.verify(t, bpc, d[5 * bpc:], stored, 5) == (native.OK, -1)
         assert oracle.verify(t, bpc, bad, stored, 0) == (1, (17 * MIB + 5) // bpc)
+
+
+def test_device_entry_points_under_graph_capture(gpu):
+    # the device-resident calls only enqueue kernels (and one memset) on the caller's stream: they can be
+    # captured into a HIP graph and replayed on new data
+    torch, native, L = gpu
+    n_chunks, chunk, bpc = 8, 4 * MIB, 16384
+    d = torch.zeros(n_chunks * chunk, dtype=torch.uint8, device="cuda")
+    wpc = chunk // bpc
+    sums = torch.zeros(n_chunks * wpc * 4, dtype=torch.uint8, device="cuda")
+    big = torch.zeros(n_chunks * 4 * 4, dtype=torch.uint8, device="cuda")
+    fm = torch.zeros(n_chunks, dtype=torch.int64, device="cuda")
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            st = torch.cuda.current_stream().cuda_stream
+            native.check(L.ozcs_compute_device(0, oracle.CRC32C, bpc, d.data_ptr(), chunk, n_chunks, chunk, sums.data_ptr(), sums.numel(), st))
+            native.check(L.ozcs_compute_device(0, oracle.CRC32, MIB, d.data_ptr(), chunk, n_chunks, chunk, big.data_ptr(), big.numel(), st))
+            native.check(L.ozcs_verify_device(0, oracle.CRC32C, bpc, d.data_ptr(), chunk, n_chunks, chunk, sums.data_ptr(), wpc * 4, wpc, 0,
+                                              fm.data_ptr(), st))
+    torch.cuda.current_stream().wait_stream(s)
+    for seed in (1, 2):
+        host = oracle.splitmix64(600 + seed, n_chunks * chunk)
+        d.copy_(torch.from_numpy(host))
+        g.replay()
+        torch.cuda.synchronize()
+        assert bytes(sums.cpu().numpy()) == oracle_chunks(oracle.CRC32C, bpc, host, chunk, n_chunks, chunk)
+        assert bytes(big.cpu().numpy()) == oracle_chunks(oracle.CRC32, MIB, host, chunk, n_chunks, chunk)
+        assert fm.cpu().tolist() == [-1] * n_chunks
