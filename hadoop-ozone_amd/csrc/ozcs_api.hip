@@ -10,6 +10,7 @@
 
 #include <atomic>
 #include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -372,8 +373,14 @@ static void batch_on_device(int device, ozcs_chunk* chunks, uint32_t lo, uint32_
           }
           std::vector<hipError_t> errs(nthreads, hipSuccess);
           std::vector<std::thread> th;
-          for (size_t t = 1; t < nthreads; t++)
-            if (cut[t] < cut[t + 1]) th.emplace_back(gather, cut[t], cut[t + 1], &errs[t]);
+          for (size_t t = 1; t < nthreads; t++) {
+            if (cut[t] >= cut[t + 1]) continue;
+            try {
+              th.emplace_back(gather, cut[t], cut[t + 1], &errs[t]);
+            } catch (...) {  // no thread to be had: this one gathers that share too
+              gather(cut[t], cut[t + 1], &errs[t]);
+            }
+          }
           if (cut[0] < cut[1]) gather(cut[0], cut[1], &errs[0]);
           for (auto& t : th) t.join();
           for (hipError_t x : errs)
@@ -635,7 +642,7 @@ int ozcs_verify_device(int device, int type, uint32_t bpc, const void* d_data, u
 }
 
 int ozcs_compute(int type, uint32_t bpc, const void* data, uint64_t len, void* sums_out, uint64_t sums_cap,
-                 uint64_t* n_sums) {
+                 uint64_t* n_sums) try {
   if (n_sums) *n_sums = 0;
   int rc = check_type_bpc(type, bpc);
   if (rc != OZCS_OK) return rc;
@@ -658,10 +665,14 @@ int ozcs_compute(int type, uint32_t bpc, const void* data, uint64_t len, void* s
   rc = compute_host_on(pick_device(), type, bpc, data, len, sums_out, n, ds);
   if (rc == OZCS_OK && n_sums) *n_sums = n;
   return rc;
+} catch (const std::bad_alloc&) {
+  return fail(OZCS_ENOMEM, "out of host memory in %s", "ozcs_compute");
+} catch (...) {
+  return fail(OZCS_EHIP, "unexpected failure in %s", "ozcs_compute");
 }
 
 int ozcs_verify(int type, uint32_t bpc, const void* data, uint64_t len, const void* expected,
-                uint64_t n_expected, uint64_t start_index, int64_t* first_mismatch) {
+                uint64_t n_expected, uint64_t start_index, int64_t* first_mismatch) try {
   if (first_mismatch) *first_mismatch = -1;
   int rc = check_type_bpc(type, bpc);
   if (rc != OZCS_OK) return rc;
@@ -731,9 +742,13 @@ int ozcs_verify(int type, uint32_t bpc, const void* data, uint64_t len, const vo
   }
   if (first_mismatch) *first_mismatch = fm;
   return OZCS_OK;
+} catch (const std::bad_alloc&) {
+  return fail(OZCS_ENOMEM, "out of host memory in %s", "ozcs_verify");
+} catch (...) {
+  return fail(OZCS_EHIP, "unexpected failure in %s", "ozcs_verify");
 }
 
-int ozcs_compute_batch(ozcs_chunk* chunks, uint32_t n_chunks) {
+int ozcs_compute_batch(ozcs_chunk* chunks, uint32_t n_chunks) try {
   if (n_chunks == 0) return OZCS_OK;
   if (!chunks) return fail(OZCS_EINVAL, "null chunk list");
   int rc = ensure_init();
@@ -751,16 +766,25 @@ int ozcs_compute_batch(ozcs_chunk* chunks, uint32_t n_chunks) {
     std::vector<std::thread> th;
     for (size_t d = 0; d < ndev; d++) {
       const uint32_t lo = (uint32_t)((uint64_t)n_chunks * d / ndev), hi = (uint32_t)((uint64_t)n_chunks * (d + 1) / ndev);
-      if (lo < hi) th.emplace_back(batch_on_device, g.devs[d].id, chunks, lo, hi);
+      if (lo >= hi) continue;
+      try {
+        th.emplace_back(batch_on_device, g.devs[d].id, chunks, lo, hi);
+      } catch (...) {  // no thread to be had: the caller's thread serves that device's share
+        batch_on_device(g.devs[d].id, chunks, lo, hi);
+      }
     }
     for (auto& t : th) t.join();
   }
   for (uint32_t i = 0; i < n_chunks; i++)
     if (chunks[i].status != OZCS_OK) return chunks[i].status;
   return OZCS_OK;
+} catch (const std::bad_alloc&) {
+  return fail(OZCS_ENOMEM, "out of host memory in %s", "ozcs_compute_batch");
+} catch (...) {
+  return fail(OZCS_EHIP, "unexpected failure in %s", "ozcs_compute_batch");
 }
 
-int ozcs_verify_batch(ozcs_vchunk* v, uint32_t n_chunks) {
+int ozcs_verify_batch(ozcs_vchunk* v, uint32_t n_chunks) try {
   if (n_chunks == 0) return OZCS_OK;
   if (!v) return fail(OZCS_EINVAL, "null chunk list");
   // Hash everything that needs hashing through the batched compute path into scratch digests, then compare
@@ -809,6 +833,10 @@ int ozcs_verify_batch(ozcs_vchunk* v, uint32_t n_chunks) {
   for (uint32_t i = 0; i < n_chunks; i++)
     if (v[i].status != OZCS_OK) return v[i].status;
   return OZCS_OK;
+} catch (const std::bad_alloc&) {
+  return fail(OZCS_ENOMEM, "out of host memory in %s", "ozcs_verify_batch");
+} catch (...) {
+  return fail(OZCS_EHIP, "unexpected failure in %s", "ozcs_verify_batch");
 }
 
 }  // extern "C"
