@@ -94,7 +94,8 @@ int flush_deferred(ozcs_pipe* p) {
     while (i < p->deferred.size() && rc == OZCS_OK) {
       DigestJobList jl{};
       jl.algo = algo;
-      std::vector<int> batch;
+      int batch[kMaxDigestJobs];
+      int nbatch = 0;
       for (; i < p->deferred.size() && jl.n_jobs < (uint32_t)kMaxDigestJobs; i++) {
         Slot& s = p->slots[p->deferred[i]];
         if (s.type != type) continue;
@@ -105,18 +106,18 @@ int flush_deferred(ozcs_pipe* p) {
         j.bpc = s.bpc;
         j.first_window = jl.n_windows;
         jl.n_windows += (uint32_t)s.n_sums;
-        batch.push_back(p->deferred[i]);
+        batch[nbatch++] = p->deferred[i];
       }
-      if (batch.empty()) break;
+      if (nbatch == 0) break;
       hipError_t e = hipSuccess;
-      for (int t : batch)
-        if (e == hipSuccess) e = hipStreamWaitEvent(p->s_digest, p->slots[t].copied, 0);
+      for (int bi = 0; bi < nbatch; bi++)
+        if (e == hipSuccess) e = hipStreamWaitEvent(p->s_digest, p->slots[batch[bi]].copied, 0);
       if (e == hipSuccess) e = digest_launch_jobs(jl, p->dev.num_cus, p->s_digest);
       Slot& lead = p->slots[batch[0]];
       if (e == hipSuccess) e = hipEventRecord(lead.hashed, p->s_digest);
       if (e == hipSuccess) e = hipStreamWaitEvent(p->s_digest_d2h, lead.hashed, 0);
-      for (int t : batch) {
-        Slot& s = p->slots[t];
+      for (int bi = 0; bi < nbatch; bi++) {
+        Slot& s = p->slots[batch[bi]];
         if (e == hipSuccess) e = hipMemcpyAsync(s.h_sums, s.d_sums, s.sums_len, hipMemcpyDeviceToHost, p->s_digest_d2h);
         if (e == hipSuccess) e = hipEventRecord(s.done, p->s_digest_d2h);
         s.deferred = false;
@@ -127,9 +128,9 @@ int flush_deferred(ozcs_pipe* p) {
         rc = fail_hip(e, "pipe digest batch");
         (void)hipStreamSynchronize(p->s_digest);
         (void)hipStreamSynchronize(p->s_digest_d2h);
-        for (int t : batch) {
-          p->slots[t].status = rc;
-          (void)hipEventRecord(p->slots[t].done, p->s_digest_d2h);
+        for (int bi = 0; bi < nbatch; bi++) {
+          p->slots[batch[bi]].status = rc;
+          (void)hipEventRecord(p->slots[batch[bi]].done, p->s_digest_d2h);
         }
       } else {
         s_launches.fetch_add(1, std::memory_order_relaxed);
@@ -172,7 +173,13 @@ int ozcs_pipe_create(int device, uint32_t n_slots, uint64_t slot_bytes, ozcs_pip
   p->dev = *dev;
   p->slot_bytes = slot_bytes;
   p->sums_bytes = sums_capacity(slot_bytes);
-  p->slots.resize(n_slots);
+  try {
+    p->slots.resize(n_slots);
+    p->deferred.reserve(n_slots);  // so that parking a digest slot later never allocates
+  } catch (...) {
+    delete p;
+    return fail(OZCS_ENOMEM, "out of host memory");
+  }
   hipError_t e = hipStreamCreateWithFlags(&p->s_h2d, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->s_kernel, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->s_d2h, hipStreamNonBlocking);
