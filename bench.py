@@ -24,7 +24,7 @@ MIB = 1 << 20
 BLOCK_BYTES = 256 * MIB   # ozone.scm.block.size, OzoneConfigKeys.java:115-116
 CHUNK_BYTES = 4 * MIB     # ozone.scm.chunk.size / stream buffer, OzoneClientConfig.java:50-55
 HBM_PEAK_GBPS = 8000.0    # MI355X HBM3E datasheet peak
-MEASURED_NT_READ_GBPS = 7020.0  # pure non-temporal streaming read in the kernel's access pattern (profiles/r01_hbm_read_microbench.log)
+MEASURED_NT_READ_GBPS = 7070.0  # pure non-temporal streaming read in the kernel's access pattern (profiles/r01_hbm_read_microbench.log)
 
 
 def shard_blocks(total_blocks, rank, world):

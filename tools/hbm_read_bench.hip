@@ -79,6 +79,28 @@ __global__ __launch_bounds__(1024) void read_wave_windows_policy(const uint8_t* 
   if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = 1;
 }
 
+// exactly the CRC kernel's pattern: G wavefronts share a window, stripe = 2*G KiB, each wavefront reads two 1 KiB
+// rows of every stripe, one stripe prefetched ahead (non-temporal loads)
+template <int G>
+__global__ __launch_bounds__(1024) void read_crc_pattern(const uint8_t* p, uint64_t nwin, uint64_t win, uint32_t* out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = wave / G, wsub = wave % G;
+  constexpr uint64_t kStripe = 2048ull * G;
+  u32x4 acc = {0, 0, 0, 0};
+  for (uint64_t g = (uint64_t)blockIdx.x * (16 / G) + sub; g < nwin; g += (uint64_t)gridDim.x * (16 / G)) {
+    const uint8_t* q = p + g * win + 2048 * wsub + 16 * lane;
+    u32x4 a = __builtin_nontemporal_load((gptr)q), b = __builtin_nontemporal_load((gptr)(q + 1024));
+    for (uint64_t o = kStripe; o < win; o += kStripe) {
+      const u32x4 na = __builtin_nontemporal_load((gptr)(q + o)), nb = __builtin_nontemporal_load((gptr)(q + o + 1024));
+      acc ^= a ^ b;
+      a = na;
+      b = nb;
+    }
+    acc ^= a ^ b;
+  }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = 1;
+}
+
 // 1024-thread blocks, whole block streams one window in 16 KiB stripes
 template <int UNROLL, bool NT>
 __global__ __launch_bounds__(1024) void read_block_windows(const uint8_t* p, uint64_t nwin, uint64_t win, uint32_t* out) {
@@ -148,6 +170,9 @@ int main(int argc, char** argv) {
   timeit("wave-windows asm nt staggered", bytes, [&] { read_wave_windows_policy<8, 1, true><<<256, 1024>>>(d, nwin, win, out); });
   timeit("wave-windows asm nt unroll4", bytes, [&] { read_wave_windows_policy<4, 1, false><<<256, 1024>>>(d, nwin, win, out); });
   timeit("wave-windows asm nt unroll2", bytes, [&] { read_wave_windows_policy<2, 1, false><<<256, 1024>>>(d, nwin, win, out); });
+  timeit("crc pattern G=1 (prefetch 1, nt)", bytes, [&] { read_crc_pattern<1><<<256, 1024>>>(d, nwin, win, out); });
+  timeit("crc pattern G=2 (prefetch 1, nt)", bytes, [&] { read_crc_pattern<2><<<256, 1024>>>(d, nwin, win, out); });
+  timeit("crc pattern G=4 (prefetch 1, nt)", bytes, [&] { read_crc_pattern<4><<<256, 1024>>>(d, nwin, win, out); });
   timeit("hipMemsetAsync (write only)", bytes, [&] { (void)hipMemsetAsync(d, 1, bytes, 0); });
   return 0;
 }
