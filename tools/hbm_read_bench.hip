@@ -101,6 +101,37 @@ __global__ __launch_bounds__(1024) void read_crc_pattern(const uint8_t* p, uint6
   if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = 1;
 }
 
+// the same with ROWS 1 KiB rows per wavefront and stripe, and PF stripes ahead
+template <int G, int ROWS, int PF>
+__global__ __launch_bounds__(1024) void read_crc_rows(const uint8_t* p, uint64_t nwin, uint64_t win, uint32_t* out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = wave / G, wsub = wave % G;
+  constexpr uint64_t kStripe = 1024ull * ROWS * G;
+  u32x4 acc = {0, 0, 0, 0};
+  for (uint64_t g = (uint64_t)blockIdx.x * (16 / G) + sub; g < nwin; g += (uint64_t)gridDim.x * (16 / G)) {
+    const uint8_t* q = p + g * win + 1024 * ROWS * wsub + 16 * lane;
+    u32x4 buf[PF][ROWS];
+#pragma unroll
+    for (int k = 0; k < PF; k++)
+#pragma unroll
+      for (int r = 0; r < ROWS; r++) buf[k][r] = __builtin_nontemporal_load((gptr)(q + k * kStripe + 1024 * r));
+    for (uint64_t o = PF * kStripe; o < win; o += PF * kStripe) {
+#pragma unroll
+      for (int k = 0; k < PF; k++)
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+          acc ^= buf[k][r];
+          buf[k][r] = __builtin_nontemporal_load((gptr)(q + o + k * kStripe + 1024 * r));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PF; k++)
+#pragma unroll
+      for (int r = 0; r < ROWS; r++) acc ^= buf[k][r];
+  }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = 1;
+}
+
 // 1024-thread blocks, whole block streams one window in 16 KiB stripes
 template <int UNROLL, bool NT>
 __global__ __launch_bounds__(1024) void read_block_windows(const uint8_t* p, uint64_t nwin, uint64_t win, uint32_t* out) {
@@ -173,6 +204,15 @@ int main(int argc, char** argv) {
   timeit("crc pattern G=1 (prefetch 1, nt)", bytes, [&] { read_crc_pattern<1><<<256, 1024>>>(d, nwin, win, out); });
   timeit("crc pattern G=2 (prefetch 1, nt)", bytes, [&] { read_crc_pattern<2><<<256, 1024>>>(d, nwin, win, out); });
   timeit("crc pattern G=4 (prefetch 1, nt)", bytes, [&] { read_crc_pattern<4><<<256, 1024>>>(d, nwin, win, out); });
+  timeit("crc rows G=2 ROWS=1 PF=1", bytes, [&] { read_crc_rows<2, 1, 1><<<256, 1024>>>(d, nwin, win, out); });
+  timeit("crc rows G=2 ROWS=1 PF=2", bytes, [&] { read_crc_rows<2, 1, 2><<<256, 1024>>>(d, nwin, win, out); });
+  timeit("crc rows G=2 ROWS=2 PF=2", bytes, [&] { read_crc_rows<2, 2, 2><<<256, 1024>>>(d, nwin, win, out); });
+  timeit("crc rows G=2 ROWS=4 PF=1", bytes, [&] { read_crc_rows<2, 4, 1><<<256, 1024>>>(d, nwin, win, out); });
+  timeit("crc rows G=1 ROWS=4 PF=1", bytes, [&] { read_crc_rows<1, 4, 1><<<256, 1024>>>(d, nwin, win, out); });
+  timeit("crc rows G=4 ROWS=1 PF=2", bytes, [&] { read_crc_rows<4, 1, 2><<<256, 1024>>>(d, nwin, win, out); });
+  timeit("crc rows G=4 ROWS=4 PF=1", bytes, [&] { read_crc_rows<4, 4, 1><<<256, 1024>>>(d, nwin, win, out); });
+  timeit("crc rows G=8 ROWS=2 PF=1", bytes, [&] { read_crc_rows<8, 2, 1><<<256, 1024>>>(d, nwin, win, out); });
+  timeit("crc rows G=2 ROWS=2 PF=1 512 WGs", bytes, [&] { read_crc_rows<2, 2, 1><<<512, 1024>>>(d, nwin, win, out); });
   timeit("hipMemsetAsync (write only)", bytes, [&] { (void)hipMemsetAsync(d, 1, bytes, 0); });
   return 0;
 }
