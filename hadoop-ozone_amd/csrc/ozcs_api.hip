@@ -273,7 +273,7 @@ constexpr uint64_t kStagePiece = 8ull << 20;
 constexpr uint64_t kPinnedSumsMax = 32ull << 20;
 constexpr uint64_t kSplitCallBytes = 32ull << 20;  // ozcs_compute on at least this much goes through the batched path
 constexpr size_t kGatherThreads = 4;
-constexpr uint64_t kGatherBytesPerThread = 32ull << 20;  // below 64 MiB of staged data one thread gathers
+constexpr uint64_t kGatherBytesPerThread = 8ull << 20;  // below 16 MiB of staged data one thread gathers
 
 static void batch_on_device(int device, ozcs_chunk* chunks, uint32_t lo, uint32_t hi) {
   auto fail_all = [&](uint32_t a, uint32_t b, int code) {

@@ -11,7 +11,7 @@ MIB = 1 << 20
 L = native.lib()
 native.check(L.ozcs_init(0))
 rng = np.random.default_rng(0)
-for size in (4 * MIB, 64 * MIB, 1024 * MIB):
+for size in (4 * MIB, 16 * MIB, 32 * MIB, 64 * MIB, 1024 * MIB):
     d = rng.integers(0, 256, size, dtype=np.uint8)
     native.compute(native.CRC32, MIB, d)
     reps = max(2, (2048 * MIB) // size)
