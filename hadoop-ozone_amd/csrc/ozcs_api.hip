@@ -20,6 +20,12 @@
 #include "digest_kernels.h"
 #include "ozcs_internal.h"
 
+// ---- verdict words of ozcs_verify_device_noalloc: a file-scope device array instead of an allocation ----
+// Every GPU the library runs on holds its own copy of this array at its own address until the process ends.
+// In host code the name below is only a handle for hipGetSymbolAddress: the address kernels and copies use is
+// the per-device pointer resolved in ozcs_init (DeviceInfo::noalloc_verdicts), never the name.
+static __device__ __align__(256) unsigned long long scratch[OZCS_NOALLOC_MAX_CHUNKS];
+
 namespace ozcs {
 
 thread_local std::string t_err;
@@ -138,6 +144,38 @@ static hipError_t preset_verdicts(void* v, uint64_t n, hipStream_t stream) {
   if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
   preset_verdicts_kernel<<<dim3((unsigned)blocks), dim3(256), 0, stream>>>(static_cast<unsigned long long*>(v), n);
   return hipGetLastError();
+}
+
+// Resolves this device's address of the array.  Caller has made `device` current.
+static unsigned long long* resolve_noalloc_verdicts(int device) {
+  unsigned long long* ptr = nullptr;
+  const hipError_t e = hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(::scratch));
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    fail(OZCS_EHIP, "hipGetSymbolAddress(verdict array) on device %d: %s", device, hipGetErrorString(e));
+    return nullptr;
+  }
+  return ptr;
+}
+
+// One workgroup: the first chunk whose verdict word is not "none" and that word -> summary[0..1] (-1, -1 if all
+// chunks passed).
+__global__ __launch_bounds__(1024) void summarize_verdicts_kernel(const unsigned long long* v, uint32_t n,
+                                                                  long long* summary) {
+  __shared__ unsigned int first;
+  if (threadIdx.x == 0) first = 0xFFFFFFFFu;
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    if (v[i] != ~0ull) {
+      atomicMin(&first, i);
+      break;  // this thread's later chunks have larger indices
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    summary[0] = first == 0xFFFFFFFFu ? -1ll : (long long)first;
+    summary[1] = first == 0xFFFFFFFFu ? -1ll : (long long)v[first];
+  }
 }
 
 // Grow-only pinned host buffer.
@@ -557,6 +595,11 @@ int ozcs_init(uint32_t device_mask) {
     DeviceInfo d;
     d.id = i;
     d.num_cus = prop.multiProcessorCount;
+    {
+      DeviceGuard dg(i);
+      if (!dg.ok()) continue;
+      d.noalloc_verdicts = resolve_noalloc_verdicts(i);  // null: only ozcs_verify_device_noalloc is affected
+    }
     devs.push_back(d);
   }
   if (devs.empty()) return fail(OZCS_ENODEV, "no gfx950 device among %d HIP device(s)", n);
@@ -639,6 +682,42 @@ int ozcs_verify_device(int device, int type, uint32_t bpc, const void* d_data, u
   return launch_windows(*dev, type, bpc, d_data, chunk_len, n_chunks, chunk_stride, kModeVerify, nullptr, d_expected,
                         expected_stride, n_expected, start_index,
                         reinterpret_cast<unsigned long long*>(d_first_mismatch), stream);
+}
+
+int ozcs_verify_device_noalloc(int device, int type, uint32_t bpc, const void* d_data, uint64_t chunk_len,
+                               uint64_t n_chunks, uint64_t chunk_stride, const void* d_expected,
+                               uint64_t expected_stride, uint64_t n_expected, uint64_t start_index,
+                               int64_t* d_summary, void* hip_stream) {
+  int rc = check_type_bpc(type, bpc);
+  if (rc != OZCS_OK) return rc;
+  if ((rc = ensure_init()) != OZCS_OK) return rc;
+  if (!d_summary) return fail(OZCS_EINVAL, "null d_summary");
+  if (n_chunks > OZCS_NOALLOC_MAX_CHUNKS)
+    return fail(OZCS_EINVAL, "n_chunks %llu exceeds OZCS_NOALLOC_MAX_CHUNKS (%d): split the batch or use "
+                "ozcs_verify_device", (unsigned long long)n_chunks, OZCS_NOALLOC_MAX_CHUNKS);
+  const DeviceInfo* dev = find_device(device);
+  if (!dev) return fail(OZCS_ENODEV, "device %d is not initialised", device);
+  if (!dev->noalloc_verdicts) return fail(OZCS_EHIP, "the verdict array of device %d could not be resolved at init", device);
+  DeviceGuard dg(device);
+  if (!dg.ok()) return fail(OZCS_ENODEV, "cannot select device %d", device);
+  hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+  unsigned long long* verdicts = dev->noalloc_verdicts;  // the array keeps the previous call's words: preset what is used
+  const bool hashes = type != OZCS_NONE && chunk_len != 0 && n_chunks != 0;  // NONE: Checksum.java:241-244
+  if (hashes) {
+    if (!d_data || !d_expected) return fail(OZCS_EINVAL, "null device pointer");
+    if (n_chunks > 1 && chunk_stride < chunk_len) return fail(OZCS_EINVAL, "chunk_stride < chunk_len");
+    hipError_t e = preset_verdicts(verdicts, n_chunks, stream);
+    if (e != hipSuccess) return fail_hip(e, "verdict preset");
+    s_calls.fetch_add(1, std::memory_order_relaxed);
+    rc = launch_windows(*dev, type, bpc, d_data, chunk_len, n_chunks, chunk_stride, kModeVerify, nullptr, d_expected,
+                        expected_stride, n_expected, start_index, verdicts, stream);
+    if (rc != OZCS_OK) return rc;
+  }
+  summarize_verdicts_kernel<<<dim3(1), dim3(1024), 0, stream>>>(verdicts, hashes ? (uint32_t)n_chunks : 0u,
+                                                                reinterpret_cast<long long*>(d_summary));
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail_hip(e, "verdict summary");
+  return OZCS_OK;
 }
 
 int ozcs_compute(int type, uint32_t bpc, const void* data, uint64_t len, void* sums_out, uint64_t sums_cap,

@@ -13,6 +13,9 @@ namespace ozcs {
 struct DeviceInfo {
   int id = 0;
   int num_cus = 0;
+  // this device's copy of the library's file-scope verdict array (ozcs_verify_device_noalloc), resolved once
+  // at init with the device current; null if the lookup failed there
+  unsigned long long* noalloc_verdicts = nullptr;
 };
 
 // Scratch of one in-flight host-pointer call: a stream and grow-only device buffers.

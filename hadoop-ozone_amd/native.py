@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("OZCS_LIB") or os.path.join(CSRC, "libozcs.so")
 
 NONE, CRC32, CRC32C, SHA256, MD5 = 1, 2, 3, 4, 5
 OK, EINVAL, ENODEV, EHIP, ENOMEM, ERANGE, EEMPTY, EBUSY = 0, -1, -2, -3, -4, -5, -6, -7
+NOALLOC_MAX_CHUNKS = 65536
 DIGEST_SIZE = {NONE: 0, CRC32: 4, CRC32C: 4, SHA256: 32, MD5: 16}
 
 
@@ -57,6 +58,10 @@ SIGNATURES = {
                                           ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p,
                                           ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p,
                                           ctypes.c_void_p]),
+    "ozcs_verify_device_noalloc": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p,
+                                                  ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p,
+                                                  ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p,
+                                                  ctypes.c_void_p]),
     "ozcs_get_stats": (None, [ctypes.POINTER(OzcsStats)]),
     "ozcs_pipe_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p)]),
     "ozcs_pipe_destroy": (None, [ctypes.c_void_p]),

@@ -163,6 +163,26 @@ OZCS_API int ozcs_verify_device(int device, int type, uint32_t bpc, const void* 
                        uint64_t expected_stride, uint64_t n_expected, uint64_t start_index,
                        int64_t* d_first_mismatch, void* hip_stream);
 
+/* ---- device-resident verify that allocates nothing ----
+ * No counterpart in the reference.  It is for callers that cannot allocate device memory: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  ozcs_verify_device wants one caller-allocated
+ * verdict word per chunk; this variant keeps those words in a file-scope device array inside the library
+ * (OZCS_NOALLOC_MAX_CHUNKS x 8 bytes = 512 KiB, which every GPU the library is initialised on holds until the
+ * process ends) and hands back a two-word summary in caller memory, which is what the scrubber's stop-at-the-
+ * first-failure loop needs (KeyValueContainerCheck.java:294-311):
+ *   d_summary[0] = index of the first chunk with a failing window, or -1;
+ *   d_summary[1] = that chunk's first failing window index relative to its computed list (the value
+ *                  ozcs_verify_device would leave in d_first_mismatch[d_summary[0]]), or -1.
+ * Same layout arguments and the same failing-index rules as ozcs_verify_device.  The call enqueues kernels on
+ * hip_stream and calls no allocation routine; n_chunks above OZCS_NOALLOC_MAX_CHUNKS is rejected with
+ * OZCS_EINVAL.  All calls on one GPU share that GPU's array: calls that overlap on one GPU (different streams
+ * or threads without ordering between them) race; calls ordered on one stream do not. */
+#define OZCS_NOALLOC_MAX_CHUNKS 65536
+OZCS_API int ozcs_verify_device_noalloc(int device, int type, uint32_t bpc, const void* d_data, uint64_t chunk_len,
+                               uint64_t n_chunks, uint64_t chunk_stride, const void* d_expected,
+                               uint64_t expected_stride, uint64_t n_expected, uint64_t start_index,
+                               int64_t* d_summary, void* hip_stream);
+
 /* ---- asynchronous pinned pipeline: host buffer -> GPU -> digests back on the host ----
  * The write path of BlockOutputStream (BlockOutputStream.java:495-507, 645-690) fills one chunk buffer while
  * the previous one is checksummed and shipped.  A pipe gives that overlap across the PCIe link: n_slots
