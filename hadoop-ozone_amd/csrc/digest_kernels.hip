@@ -242,6 +242,20 @@ __device__ __forceinline__ uint32_t num_blocks(bool valid, uint32_t len) {
 template <class H>
 __device__ __forceinline__ void digest_core(char* stage, int lane, bool valid, uint64_t start, uint32_t len, uint32_t* h) {
   constexpr int PB = H::kStepBlocks;
+  // A lane without a window hashes a copy of the first valid lane's window (its result is never stored):
+  // the wavefront runs in lockstep anyway, and with every lane on a real window a partly filled wavefront
+  // keeps the check-free loop below -- it took 23 ms instead of 11 ms per 1 MiB MD5 window without this.
+  {
+    const uint64_t vm = __ballot(valid);
+    const int src = vm ? __builtin_ctzll(vm) : 0;
+    const uint32_t slo = __shfl((uint32_t)start, src, 64), shi = __shfl((uint32_t)(start >> 32), src, 64);
+    const uint32_t sl = __shfl(len, src, 64);
+    if (!valid && vm) {
+      start = ((uint64_t)shi << 32) | slo;
+      len = sl;
+      valid = true;
+    }
+  }
   const uint32_t nblk = num_blocks(valid, len);
   BlockLoader<PB> ld;
   ld.init(lane, valid, start, len);

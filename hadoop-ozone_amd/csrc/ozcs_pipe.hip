@@ -1,7 +1,25 @@
-// Asynchronous pinned pipeline (ozcs_pipe_*): pinned chunk slots, three streams chained by events so
-// that the host-to-device copy of one chunk, the kernel of the previous one and the digest copy-back
-// of the one before overlap.  See include/ozone_checksum.h for the contract.
+// Asynchronous pinned pipeline (ozcs_pipe_*): pinned chunk slots whose host-to-device copy, kernel and digest
+// hand-over overlap across chunks.  See include/ozone_checksum.h for the contract.
+//
+// Streams.  Copies run on one stream, CRC kernels on a second (a kernel waits for its slot's copy through an
+// event), so the copy of chunk n+1 overlaps the kernel of chunk n.  Kernels write their digests straight into
+// the slot's pinned, device-visible digest buffer: there is no copy-back and no third stream, and a slot is
+// complete when the event behind its kernel fires.
+//
+// SHA-256 / MD5.  One lane hashes one window, so the windows of one chunk fill a few lanes of one wavefront
+// for as long as one window takes (about 11 ms for a 1 MiB MD5 window), and the chip has room for thousands
+// of such wavefronts side by side.  Digest slots are therefore parked after their copy and launched in
+// batches (one job-list launch per algorithm and batch) on a pool of low-priority digest streams: a batch
+// starts as soon as a digest stream is idle, takes everything of its algorithm that has gathered by then, and
+// several batches run concurrently.  The digest streams are low-priority so that they get hardware queues of
+// their own (the runtime keeps a queue pool per priority) and a long digest kernel never sits in front of a
+// CRC kernel.
+//
+// Tickets.  ticket = slot number | tenancy epoch << 12.  The epoch changes with every acquisition of the slot,
+// so a ticket names one tenancy: a thread that waits without the lock cannot complete a later tenancy of the
+// same slot, and a ticket whose tenancy has ended is recognised as such.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -17,23 +35,65 @@ using namespace ozcs;
 
 namespace {
 
-enum SlotState { kFree = 0, kAcquired = 1, kInFlight = 2 };
+enum SlotState {
+  kFree = 0,
+  kAcquired = 1,  // handed to a producer, not yet submitted
+  kInFlight = 2,  // submitted; copy / kernel pending, or parked for a digest batch
+  kDone = 3       // digests are in h_sums; waiting for the ticket's holder to pick them up
+};
+
+constexpr int kSlotBits = 12;  // ozcs_pipe_create caps n_slots at 4096
+constexpr int kSlotMask = (1 << kSlotBits) - 1;
+constexpr uint32_t kEpochMask = (1u << 18) - 1;
+constexpr int kMaxDigestStreams = 8;
 
 struct Slot {
-  void* h_data = nullptr;   // pinned, slot_bytes
-  void* d_data = nullptr;   // device, slot_bytes
-  void* h_sums = nullptr;   // pinned, sums_bytes
-  void* d_sums = nullptr;   // device, sums_bytes
-  hipEvent_t copied = nullptr, hashed = nullptr, done = nullptr;
+  uint8_t* h_data = nullptr;  // pinned, slot_bytes
+  uint8_t* d_data = nullptr;  // device, slot_bytes
+  uint8_t* h_sums = nullptr;  // pinned, sums_bytes; kernels write it through d_sums_alias
+  uint8_t* d_sums_alias = nullptr;  // device-side address of h_sums
+  hipEvent_t copied = nullptr, done = nullptr;
   int state = kFree;
-  bool deferred = false;   // SHA-256 / MD5 slot whose kernel waits for a batch (see flush_deferred)
+  bool deferred = false;  // digest slot parked for a batch
+  int batch = -1;         // digest stream whose running batch hashes this slot (launched digest slots)
+  uint32_t epoch = 0;
   int type = 0;
   uint32_t bpc = 0;
   uint64_t len = 0;
   void* user_sums = nullptr;
   uint64_t n_sums = 0, sums_len = 0;
   int status = OZCS_OK;
+  // outcome of the last tenancy that ended, for a holder that lost a race against ozcs_pipe_drain /
+  // ozcs_pipe_next_completed on another thread
+  uint32_t last_epoch = 0;
+  int last_status = OZCS_OK;
+  uint64_t last_n_sums = 0;
+  bool has_last = false;
+  // threads inside ozcs_pipe_wait for a tenancy of this slot, waiting without the lock: the slot is not let
+  // again before they have looked at the outcome, so the record above is always the one they need
+  int waiters = 0;
 };
+
+struct DigestStream {
+  hipStream_t stream = nullptr;
+  hipEvent_t done = nullptr;  // end of the batch running on this stream
+  bool running = false;
+  std::vector<int> slots;     // slots of that batch
+};
+
+int make_ticket(int slot, uint32_t epoch) { return slot | (int)((epoch & kEpochMask) << kSlotBits); }
+
+// Fault injection for tests (read once): OZCS_FAULT_PIPE_DIGEST_LAUNCH = k makes the k-th digest batch launch of
+// the process fail as if the runtime had refused it.
+const int g_fault_digest_launch = getenv("OZCS_FAULT_PIPE_DIGEST_LAUNCH") ? atoi(getenv("OZCS_FAULT_PIPE_DIGEST_LAUNCH")) : 0;
+std::atomic<int> g_digest_launches{0};
+// Tuning override for experiments (read once): number of digest streams per pipe.  Measured on MI355X, CRC32 : MD5
+// = 3 : 1 at 1 MiB windows, 64 slots: 1 / 2 / 4 / 8 low-priority streams give 43.7 / 45.0 / 37.2 / 30.3 GB/s (the
+// link gives 45): two batches side by side keep the hashing ahead of the link, more streams than hardware
+// queues get in the way of the copy and CRC streams.
+const int g_digest_streams = getenv("OZCS_PIPE_DIGEST_STREAMS") ? atoi(getenv("OZCS_PIPE_DIGEST_STREAMS")) : 2;
+// ... and whether they are created with the lowest stream priority (default) or the normal one (0).
+const int g_digest_low_prio = getenv("OZCS_PIPE_DIGEST_LOW_PRIO") ? atoi(getenv("OZCS_PIPE_DIGEST_LOW_PRIO")) : 1;
 
 }  // namespace
 
@@ -41,12 +101,17 @@ struct ozcs_pipe {
   int device = 0;
   DeviceInfo dev;
   uint64_t slot_bytes = 0, sums_bytes = 0;
-  hipStream_t s_h2d = nullptr, s_kernel = nullptr, s_d2h = nullptr;
-  hipStream_t s_digest = nullptr, s_digest_d2h = nullptr;  // SHA-256 / MD5 batches: milliseconds each, kept off the CRC streams
-  hipEvent_t digest_done = nullptr;                        // end of the digest batch in flight
-  bool digest_running = false;
+  hipStream_t s_h2d = nullptr, s_kernel = nullptr;
+  std::vector<DigestStream> digest;
+  uint8_t* h_data_all = nullptr;
+  uint8_t* d_data_all = nullptr;
+  uint8_t* h_sums_all = nullptr;
   std::vector<Slot> slots;
-  std::vector<int> deferred;  // tickets of digest slots copied to the device but not yet hashed
+  std::vector<int> deferred;   // digest slots copied (or being copied) to the device, not yet launched; FIFO
+  std::vector<int> crc_fifo;   // launched CRC / NONE slots in submission order (they complete in that order)
+  size_t crc_head = 0;         // first live entry of crc_fifo
+  uint32_t in_flight = 0;      // slots in kInFlight
+  uint32_t done_unclaimed = 0; // slots in kDone
   std::mutex mu;
 };
 
@@ -56,17 +121,6 @@ namespace {
 // digest buffer is sized for windows of at least 512 bytes and submit rejects what does not fit
 uint64_t sums_capacity(uint64_t slot_bytes) { return (slot_bytes / 512 + 1) * 32; }
 
-void free_slot(Slot& s) {
-  if (s.h_data) (void)hipHostFree(s.h_data);
-  if (s.d_data) (void)hipFree(s.d_data);
-  if (s.h_sums) (void)hipHostFree(s.h_sums);
-  if (s.d_sums) (void)hipFree(s.d_sums);
-  if (s.copied) (void)hipEventDestroy(s.copied);
-  if (s.hashed) (void)hipEventDestroy(s.hashed);
-  if (s.done) (void)hipEventDestroy(s.done);
-  s = Slot();
-}
-
 // hipEventQuery that does not leave hipErrorNotReady behind as the thread's last error (the caller's own
 // HIP code would otherwise find it there).
 hipError_t query_event(hipEvent_t ev) {
@@ -75,80 +129,212 @@ hipError_t query_event(hipEvent_t ev) {
   return e;
 }
 
-// Completes a slot whose `done` event has fired: hands the digests over and frees the slot.
-void retire(Slot& s) {
-  if (s.status == OZCS_OK && s.sums_len) memcpy(s.user_sums, s.h_sums, s.sums_len);
-  s.state = kFree;
+void mark_done(ozcs_pipe* p, Slot& s, int status) {
+  if (s.state != kInFlight) return;
+  if (status != OZCS_OK) s.status = status;
+  s.state = kDone;
+  s.deferred = false;
+  s.batch = -1;
+  p->in_flight--;
+  p->done_unclaimed++;
 }
 
-// SHA-256 and MD5 run one window per lane, so the four windows of one chunk would occupy four lanes of
-// one wavefront for milliseconds.  Digest slots are therefore parked after their host-to-device copy and
-// hashed together, one launch per algorithm over up to kMaxDigestJobs chunks, when enough have gathered
-// or when somebody needs a result or a slot.  Caller holds p->mu and has selected the device.
-int flush_deferred(ozcs_pipe* p) {
-  if (p->deferred.empty()) return OZCS_OK;
-  int rc = OZCS_OK;
-  for (int algo = 0; algo < 2 && rc == OZCS_OK; algo++) {
-    const int type = algo == kAlgoSha256 ? OZCS_SHA256 : OZCS_MD5;
-    size_t i = 0;
-    while (i < p->deferred.size() && rc == OZCS_OK) {
-      DigestJobList jl{};
-      jl.algo = algo;
-      int batch[kMaxDigestJobs];
-      int nbatch = 0;
-      for (; i < p->deferred.size() && jl.n_jobs < (uint32_t)kMaxDigestJobs; i++) {
-        Slot& s = p->slots[p->deferred[i]];
-        if (s.type != type) continue;
-        DigestJob& j = jl.jobs[jl.n_jobs++];
-        j.data = static_cast<const uint8_t*>(s.d_data);
-        j.len = s.len;
-        j.sums = static_cast<uint8_t*>(s.d_sums);
-        j.bpc = s.bpc;
-        j.first_window = jl.n_windows;
-        jl.n_windows += (uint32_t)s.n_sums;
-        batch[nbatch++] = p->deferred[i];
-      }
-      if (nbatch == 0) break;
-      hipError_t e = hipSuccess;
-      for (int bi = 0; bi < nbatch; bi++)
-        if (e == hipSuccess) e = hipStreamWaitEvent(p->s_digest, p->slots[batch[bi]].copied, 0);
-      if (e == hipSuccess) e = digest_launch_jobs(jl, p->dev.num_cus, p->s_digest);
-      Slot& lead = p->slots[batch[0]];
-      if (e == hipSuccess) e = hipEventRecord(lead.hashed, p->s_digest);
-      if (e == hipSuccess) e = hipStreamWaitEvent(p->s_digest_d2h, lead.hashed, 0);
-      for (int bi = 0; bi < nbatch; bi++) {
-        Slot& s = p->slots[batch[bi]];
-        if (e == hipSuccess) e = hipMemcpyAsync(s.h_sums, s.d_sums, s.sums_len, hipMemcpyDeviceToHost, p->s_digest_d2h);
-        if (e == hipSuccess) e = hipEventRecord(s.done, p->s_digest_d2h);
-        s.deferred = false;
-      }
-      if (e == hipSuccess) e = hipEventRecord(p->digest_done, p->s_digest_d2h);
-      if (e == hipSuccess) p->digest_running = true;
-      if (e != hipSuccess) {
-        rc = fail_hip(e, "pipe digest batch");
-        (void)hipStreamSynchronize(p->s_digest);
-        (void)hipStreamSynchronize(p->s_digest_d2h);
-        for (int bi = 0; bi < nbatch; bi++) {
-          p->slots[batch[bi]].status = rc;
-          (void)hipEventRecord(p->slots[batch[bi]].done, p->s_digest_d2h);
-        }
-      } else {
-        s_launches.fetch_add(1, std::memory_order_relaxed);
-        s_windows.fetch_add(jl.n_windows, std::memory_order_relaxed);
-      }
-    }
+// Ends a tenancy whose slot is kDone: hands the digests over and frees the slot.
+void retire(ozcs_pipe* p, Slot& s) {
+  if (s.status == OZCS_OK && s.sums_len) memcpy(s.user_sums, s.h_sums, s.sums_len);
+  s.last_epoch = s.epoch;
+  s.last_status = s.status;
+  s.last_n_sums = s.n_sums;
+  s.has_last = true;
+  s.state = kFree;
+  p->done_unclaimed--;
+}
+
+// Moves every slot whose GPU work has finished from kInFlight to kDone.  CRC slots complete in submission
+// order (one kernel stream), so only the head of their FIFO is queried; digest slots complete batch by batch.
+// Caller holds p->mu and has selected the device.
+void reap(ozcs_pipe* p) {
+  while (p->crc_head < p->crc_fifo.size()) {
+    Slot& s = p->slots[p->crc_fifo[p->crc_head]];
+    const hipError_t e = query_event(s.done);
+    if (e == hipErrorNotReady) break;
+    mark_done(p, s, e == hipSuccess ? OZCS_OK : fail_hip(e, "pipe completion"));
+    p->crc_head++;
   }
-  p->deferred.clear();
+  if (p->crc_head == p->crc_fifo.size()) {
+    p->crc_fifo.clear();
+    p->crc_head = 0;
+  } else if (p->crc_head >= 1024) {
+    p->crc_fifo.erase(p->crc_fifo.begin(), p->crc_fifo.begin() + (long)p->crc_head);
+    p->crc_head = 0;
+  }
+  for (DigestStream& d : p->digest) {
+    if (!d.running) continue;
+    const hipError_t e = query_event(d.done);
+    if (e == hipErrorNotReady) continue;
+    const int status = e == hipSuccess ? OZCS_OK : fail_hip(e, "pipe digest batch");
+    for (int t : d.slots) mark_done(p, p->slots[t], status);
+    d.slots.clear();
+    d.running = false;
+  }
+}
+
+// Launches parked digest slots on idle digest streams: per idle stream one batch of one algorithm (the one of
+// the oldest parked slot), up to kMaxDigestJobs chunks.  Slots that find no idle stream stay parked.  If the
+// runtime refuses a launch, every slot of that batch completes with the error (nothing was queued for it).
+// Caller holds p->mu, has selected the device and has called reap().
+int launch_deferred(ozcs_pipe* p) {
+  int rc = OZCS_OK;
+  for (DigestStream& d : p->digest) {
+    if (p->deferred.empty()) break;
+    if (d.running) continue;
+    const int type = p->slots[p->deferred[0]].type;
+    DigestJobList jl{};
+    jl.algo = type == OZCS_SHA256 ? kAlgoSha256 : kAlgoMd5;
+    d.slots.clear();
+    size_t keep = 0;
+    int newest = -1;  // the batch's most recently submitted slot: copies are queued in submission order
+    for (size_t i = 0; i < p->deferred.size(); i++) {
+      const int t = p->deferred[i];
+      Slot& s = p->slots[t];
+      if (s.type != type || jl.n_jobs == (uint32_t)kMaxDigestJobs) {
+        p->deferred[keep++] = t;
+        continue;
+      }
+      DigestJob& j = jl.jobs[jl.n_jobs++];
+      j.data = s.d_data;
+      j.len = s.len;
+      j.sums = s.d_sums_alias;
+      j.bpc = s.bpc;
+      j.first_window = jl.n_windows;
+      jl.n_windows += (uint32_t)s.n_sums;
+      d.slots.push_back(t);
+      newest = t;
+    }
+    p->deferred.resize(keep);
+    hipError_t e = hipStreamWaitEvent(d.stream, p->slots[newest].copied, 0);
+    if (e == hipSuccess) {
+      const int k = g_digest_launches.fetch_add(1, std::memory_order_relaxed) + 1;
+      e = (g_fault_digest_launch && k == g_fault_digest_launch) ? hipErrorLaunchFailure
+                                                                : digest_launch_jobs(jl, p->dev.num_cus, d.stream);
+    }
+    if (e == hipSuccess) e = hipEventRecord(d.done, d.stream);
+    if (e != hipSuccess) {
+      rc = fail_hip(e, "pipe digest batch");
+      (void)hipStreamSynchronize(d.stream);  // whatever part of the batch was queued has ended before its slots are reused
+      for (int t : d.slots) mark_done(p, p->slots[t], rc);
+      d.slots.clear();
+      continue;
+    }
+    for (int t : d.slots) {
+      Slot& s = p->slots[t];
+      s.deferred = false;
+      s.batch = (int)(&d - p->digest.data());
+    }
+    d.running = true;
+    s_launches.fetch_add(1, std::memory_order_relaxed);
+    s_windows.fetch_add(jl.n_windows, std::memory_order_relaxed);
+  }
   return rc;
 }
 
-// Launches the parked digest slots when the previous digest batch has finished (so exactly one batch runs
-// while the next gathers) or when `limit` slots have gathered.  Caller holds p->mu.
-int maybe_flush(ozcs_pipe* p, size_t limit) {
-  if (p->deferred.empty()) return OZCS_OK;
-  if (p->digest_running && query_event(p->digest_done) == hipSuccess) p->digest_running = false;
-  if (!p->digest_running || p->deferred.size() >= limit) return flush_deferred(p);
-  return OZCS_OK;
+// An event whose completion brings the pipe forward when nothing is done yet: the oldest CRC slot's, else a
+// running digest batch's (the one of `prefer` if it runs in one).  Null when no GPU work is queued at all.
+hipEvent_t progress_event(ozcs_pipe* p, const Slot* prefer) {
+  if (prefer && prefer->state == kInFlight && !prefer->deferred) {
+    if (prefer->batch >= 0) return p->digest[prefer->batch].done;
+    return prefer->done;
+  }
+  if (p->crc_head < p->crc_fifo.size()) return p->slots[p->crc_fifo[p->crc_head]].done;
+  for (DigestStream& d : p->digest)
+    if (d.running) return d.done;
+  return nullptr;
+}
+
+void destroy_pipe(ozcs_pipe* p) {
+  DeviceGuard dg(p->device);
+  if (p->s_h2d) (void)hipStreamSynchronize(p->s_h2d);
+  if (p->s_kernel) (void)hipStreamSynchronize(p->s_kernel);
+  for (DigestStream& d : p->digest)
+    if (d.stream) (void)hipStreamSynchronize(d.stream);
+  for (Slot& s : p->slots) {
+    if (s.copied) (void)hipEventDestroy(s.copied);
+    if (s.done) (void)hipEventDestroy(s.done);
+  }
+  for (DigestStream& d : p->digest) {
+    if (d.done) (void)hipEventDestroy(d.done);
+    if (d.stream) (void)hipStreamDestroy(d.stream);
+  }
+  if (p->h_data_all) (void)hipHostFree(p->h_data_all);
+  if (p->d_data_all) (void)hipFree(p->d_data_all);
+  if (p->h_sums_all) (void)hipHostFree(p->h_sums_all);
+  if (p->s_h2d) (void)hipStreamDestroy(p->s_h2d);
+  if (p->s_kernel) (void)hipStreamDestroy(p->s_kernel);
+  delete p;
+}
+
+// Resolves a ticket to its slot.  Returns OZCS_OK with *stale = false for the slot's current tenancy,
+// OZCS_OK with *stale = true when that tenancy has ended and its outcome is still on record, else OZCS_EINVAL.
+int resolve(ozcs_pipe* p, int ticket, Slot** out, bool* stale) {
+  const int idx = ticket & kSlotMask;
+  if (ticket < 0 || (size_t)idx >= p->slots.size()) return fail(OZCS_EINVAL, "bad ticket %d", ticket);
+  Slot& s = p->slots[idx];
+  const uint32_t epoch = ((uint32_t)ticket >> kSlotBits) & kEpochMask;
+  *out = &s;
+  if (s.state != kFree && s.epoch == epoch) {
+    *stale = false;
+    return OZCS_OK;
+  }
+  if (s.has_last && s.last_epoch == epoch) {
+    *stale = true;
+    return OZCS_OK;
+  }
+  return fail(OZCS_EINVAL, "ticket %d does not name a live slot tenancy", ticket);
+}
+
+int finish(ozcs_pipe* p, int ticket, uint64_t* n_sums, bool block) {
+  if (!p) return fail(OZCS_EINVAL, "null pipe");
+  std::unique_lock<std::mutex> lk(p->mu);
+  DeviceGuard dg(p->device);
+  for (;;) {
+    Slot* sp = nullptr;
+    bool stale = false;
+    const int rc = resolve(p, ticket, &sp, &stale);
+    if (rc != OZCS_OK) return rc;
+    Slot& s = *sp;
+    if (stale) {  // completed by ozcs_pipe_drain / ozcs_pipe_next_completed on another thread
+      if (n_sums) *n_sums = s.last_n_sums;
+      return s.last_status;
+    }
+    if (s.state == kAcquired) return fail(OZCS_EINVAL, "ticket %d was never submitted", ticket);
+    reap(p);
+    if (s.state == kInFlight && s.deferred) {
+      (void)launch_deferred(p);  // a failure is recorded in the slots it concerns
+    }
+    if (s.state == kDone) {
+      const int status = s.status;
+      if (n_sums) *n_sums = s.n_sums;
+      retire(p, s);
+      return status;
+    }
+    if (!block) return OZCS_EBUSY;
+    // Wait without the pipe's lock, so that other threads keep submitting meanwhile.  The slot may be completed
+    // and even re-let by other threads during the wait: the ticket is resolved afresh afterwards.
+    hipEvent_t ev = progress_event(p, &s);
+    if (!ev) return fail(OZCS_EHIP, "ticket %d is in flight but no GPU work is queued", ticket);
+    s.waiters++;
+    lk.unlock();
+    const hipError_t e = hipEventSynchronize(ev);
+    lk.lock();
+    s.waiters--;
+    if (e != hipSuccess) {
+      Slot* again = nullptr;
+      bool st = false;
+      if (resolve(p, ticket, &again, &st) == OZCS_OK && !st && again->state == kInFlight) {
+        mark_done(p, *again, fail_hip(e, "pipe completion"));
+      }
+    }
+  }
 }
 
 }  // namespace
@@ -157,10 +343,12 @@ extern "C" {
 
 uint64_t ozcs_pipe_slot_bytes(const ozcs_pipe* pipe) { return pipe ? pipe->slot_bytes : 0; }
 
+int ozcs_pipe_ticket_slot(int ticket) { return ticket < 0 ? -1 : (ticket & kSlotMask); }
+
 int ozcs_pipe_create(int device, uint32_t n_slots, uint64_t slot_bytes, ozcs_pipe** out) {
   if (!out) return fail(OZCS_EINVAL, "null out");
   *out = nullptr;
-  if (n_slots == 0 || n_slots > 4096 || slot_bytes == 0) return fail(OZCS_EINVAL, "bad pipe geometry");
+  if (n_slots == 0 || n_slots > (1u << kSlotBits) || slot_bytes == 0) return fail(OZCS_EINVAL, "bad pipe geometry");
   int rc = ensure_init();
   if (rc != OZCS_OK) return rc;
   const DeviceInfo* dev = find_device(device);
@@ -172,34 +360,48 @@ int ozcs_pipe_create(int device, uint32_t n_slots, uint64_t slot_bytes, ozcs_pip
   p->device = device;
   p->dev = *dev;
   p->slot_bytes = slot_bytes;
-  p->sums_bytes = sums_capacity(slot_bytes);
+  p->sums_bytes = (sums_capacity(slot_bytes) + 255) & ~(uint64_t)255;
+  const uint64_t stride = (slot_bytes + 255) & ~(uint64_t)255;
+  int n_digest = g_digest_streams < 1 ? 1 : g_digest_streams > kMaxDigestStreams ? kMaxDigestStreams : g_digest_streams;
   try {
     p->slots.resize(n_slots);
-    p->deferred.reserve(n_slots);  // so that parking a digest slot later never allocates
+    p->digest.resize((size_t)n_digest);
+    // so that parking, launching and queueing a slot later never allocate
+    p->deferred.reserve(n_slots);
+    p->crc_fifo.reserve((size_t)n_slots + 1024);
+    for (DigestStream& d : p->digest) d.slots.reserve(kMaxDigestJobs);
   } catch (...) {
     delete p;
     return fail(OZCS_ENOMEM, "out of host memory");
   }
+  int prio_low = 0, prio_high = 0;  // numerically: low priority is the larger value
+  (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
   hipError_t e = hipStreamCreateWithFlags(&p->s_h2d, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->s_kernel, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->s_d2h, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->s_digest, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->s_digest_d2h, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&p->digest_done, hipEventDisableTiming);
-  for (Slot& s : p->slots) {
-    if (e == hipSuccess) e = hipHostMalloc(&s.h_data, slot_bytes, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipMalloc(&s.d_data, slot_bytes);
-    if (e == hipSuccess) e = hipHostMalloc(&s.h_sums, p->sums_bytes, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipMalloc(&s.d_sums, p->sums_bytes);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&s.copied, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&s.hashed, hipEventDisableTiming);
+  for (DigestStream& d : p->digest) {
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&d.stream, hipStreamNonBlocking, g_digest_low_prio ? prio_low : 0);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&d.done, hipEventDisableTiming);
+  }
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&p->h_data_all), stride * n_slots, hipHostMallocDefault);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_data_all), stride * n_slots);
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&p->h_sums_all), p->sums_bytes * n_slots, hipHostMallocDefault);
+  uint8_t* d_sums_alias = nullptr;
+  if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&d_sums_alias), p->h_sums_all, 0);
+  for (size_t i = 0; i < p->slots.size(); i++) {
+    Slot& s = p->slots[i];
+    if (e != hipSuccess) break;
+    s.h_data = p->h_data_all + i * stride;
+    s.d_data = p->d_data_all + i * stride;
+    s.h_sums = p->h_sums_all + i * p->sums_bytes;
+    s.d_sums_alias = d_sums_alias + i * p->sums_bytes;
+    e = hipEventCreateWithFlags(&s.copied, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
   }
   if (e != hipSuccess) {
     const int code = (e == hipErrorOutOfMemory) ? OZCS_ENOMEM : OZCS_EHIP;
-    fail(code, "pipe allocation: %s", hipGetErrorString(e));
-    ozcs_pipe_destroy(p);
-    return code;
+    (void)hipGetLastError();
+    destroy_pipe(p);
+    return fail(code, "pipe allocation: %s", hipGetErrorString(e));
   }
   *out = p;
   return OZCS_OK;
@@ -207,49 +409,41 @@ int ozcs_pipe_create(int device, uint32_t n_slots, uint64_t slot_bytes, ozcs_pip
 
 void ozcs_pipe_destroy(ozcs_pipe* p) {
   if (!p) return;
-  DeviceGuard dg(p->device);
-  if (p->s_h2d) (void)hipStreamSynchronize(p->s_h2d);
-  if (p->s_kernel) (void)hipStreamSynchronize(p->s_kernel);
-  if (p->s_d2h) (void)hipStreamSynchronize(p->s_d2h);
-  if (p->s_digest) (void)hipStreamSynchronize(p->s_digest);
-  if (p->s_digest_d2h) (void)hipStreamSynchronize(p->s_digest_d2h);
-  for (Slot& s : p->slots) free_slot(s);
-  if (p->s_digest) (void)hipStreamDestroy(p->s_digest);
-  if (p->s_digest_d2h) (void)hipStreamDestroy(p->s_digest_d2h);
-  if (p->digest_done) (void)hipEventDestroy(p->digest_done);
-  if (p->s_h2d) (void)hipStreamDestroy(p->s_h2d);
-  if (p->s_kernel) (void)hipStreamDestroy(p->s_kernel);
-  if (p->s_d2h) (void)hipStreamDestroy(p->s_d2h);
-  delete p;
+  destroy_pipe(p);
 }
 
 int ozcs_pipe_acquire(ozcs_pipe* p, void** buf, int* ticket) {
   if (!p || !buf || !ticket) return fail(OZCS_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(p->mu);
-  DeviceGuard dg(p->device);
-  // A slot stays its ticket holder's until that ticket has been polled to completion, waited for or
-  // drained: a finished slot is never recycled behind its owner's back.
+  // A slot stays its ticket holder's until that ticket has been polled to completion, waited for, handed out by
+  // ozcs_pipe_next_completed or drained: a finished slot is never recycled behind its owner's back.
   for (size_t i = 0; i < p->slots.size(); i++) {
     Slot& s = p->slots[i];
-    if (s.state == kFree) {
+    if (s.state == kFree && s.waiters == 0) {
       s.state = kAcquired;
+      s.epoch = (s.epoch + 1) & kEpochMask;
       *buf = s.h_data;
-      *ticket = (int)i;
+      *ticket = make_ticket((int)i, s.epoch);
       return OZCS_OK;
     }
   }
-  // parked digest slots finish only once launched
-  (void)maybe_flush(p, p->slots.size() / 2 ? p->slots.size() / 2 : 1);
-  return fail(OZCS_EBUSY, "all %zu slots are in flight", p->slots.size());
+  if (!p->deferred.empty()) {  // parked digest slots finish only once launched
+    DeviceGuard dg(p->device);
+    reap(p);
+    (void)launch_deferred(p);
+  }
+  return fail(OZCS_EBUSY, "all %zu slots are held", p->slots.size());
 }
 
 int ozcs_pipe_submit_slot(ozcs_pipe* p, int ticket, int type, uint32_t bpc, uint64_t len, void* sums_out,
                           uint64_t sums_cap) {
   if (!p) return fail(OZCS_EINVAL, "null pipe");
   std::lock_guard<std::mutex> lk(p->mu);
-  if (ticket < 0 || (size_t)ticket >= p->slots.size() || p->slots[ticket].state != kAcquired)
+  Slot* sp = nullptr;
+  bool stale = false;
+  if (resolve(p, ticket, &sp, &stale) != OZCS_OK || stale || sp->state != kAcquired)
     return fail(OZCS_EINVAL, "ticket %d is not an acquired slot", ticket);
-  Slot& s = p->slots[ticket];
+  Slot& s = *sp;
   auto reject = [&](int code) { s.state = kFree; return code; };
   if (type < OZCS_NONE || type > OZCS_MD5) return reject(fail(OZCS_EINVAL, "Unrecognized ChecksumType: %d", type));
   if (type != OZCS_NONE && bpc == 0) return reject(fail(OZCS_EINVAL, "bytesPerChecksum must be positive"));
@@ -266,44 +460,48 @@ int ozcs_pipe_submit_slot(ozcs_pipe* p, int ticket, int type, uint32_t bpc, uint
   s.bpc = bpc;
   s.len = len;
   s.deferred = false;
+  s.batch = -1;
   DeviceGuard dg(p->device);
+  reap(p);
   hipError_t e = hipSuccess;
   int rc = OZCS_OK;
   const bool digest = n && (type == OZCS_SHA256 || type == OZCS_MD5);
   if (n) {
     e = hipMemcpyAsync(s.d_data, s.h_data, len, hipMemcpyHostToDevice, p->s_h2d);
     if (e == hipSuccess) e = hipEventRecord(s.copied, p->s_h2d);
-    if (e == hipSuccess) {
-      s_h2d.fetch_add(len, std::memory_order_relaxed);
-      s_d2h.fetch_add(n * ds, std::memory_order_relaxed);
-      s_bytes.fetch_add(digest ? len : 0, std::memory_order_relaxed);
-    }
   }
   if (digest && e == hipSuccess) {
     s.deferred = true;
     s.state = kInFlight;
-    p->deferred.push_back(ticket);
-    const size_t half = p->slots.size() / 2 ? p->slots.size() / 2 : 1;
-    return maybe_flush(p, half);
+    p->in_flight++;
+    p->deferred.push_back(ticket & kSlotMask);
+    s_h2d.fetch_add(len, std::memory_order_relaxed);
+    s_d2h.fetch_add(n * ds, std::memory_order_relaxed);
+    s_bytes.fetch_add(len, std::memory_order_relaxed);
+    (void)launch_deferred(p);  // a refused launch is reported through the tickets of its batch
+    return OZCS_OK;
   }
   if (n && e == hipSuccess) {
     e = hipStreamWaitEvent(p->s_kernel, s.copied, 0);
     if (e == hipSuccess)
-      rc = launch_windows(p->dev, type, bpc, s.d_data, len, 1, len, kModeCompute, s.d_sums, nullptr, 0, 0, 0, nullptr,
+      rc = launch_windows(p->dev, type, bpc, s.d_data, len, 1, len, kModeCompute, s.d_sums_alias, nullptr, 0, 0, 0, nullptr,
                           p->s_kernel);
-    if (e == hipSuccess && rc == OZCS_OK) e = hipEventRecord(s.hashed, p->s_kernel);
-    if (e == hipSuccess && rc == OZCS_OK) e = hipStreamWaitEvent(p->s_d2h, s.hashed, 0);
-    if (e == hipSuccess && rc == OZCS_OK) e = hipMemcpyAsync(s.h_sums, s.d_sums, n * ds, hipMemcpyDeviceToHost, p->s_d2h);
   }
-  if (e == hipSuccess && rc == OZCS_OK) e = hipEventRecord(s.done, p->s_d2h);
+  if (e == hipSuccess && rc == OZCS_OK) e = hipEventRecord(s.done, p->s_kernel);
   if (e != hipSuccess) rc = fail_hip(e, "pipe submit");
   if (rc != OZCS_OK) {
     (void)hipStreamSynchronize(p->s_h2d);
     (void)hipStreamSynchronize(p->s_kernel);
-    (void)hipStreamSynchronize(p->s_d2h);
     return reject(rc);
   }
+  if (n) {
+    s_h2d.fetch_add(len, std::memory_order_relaxed);
+    s_d2h.fetch_add(n * ds, std::memory_order_relaxed);
+  }
   s.state = kInFlight;
+  p->in_flight++;
+  p->crc_fifo.push_back(ticket & kSlotMask);
+  if (!p->deferred.empty()) (void)launch_deferred(p);  // a digest stream may have become idle meanwhile
   return OZCS_OK;
 }
 
@@ -318,60 +516,59 @@ int ozcs_pipe_submit(ozcs_pipe* p, int type, uint32_t bpc, const void* data, uin
   return ozcs_pipe_submit_slot(p, *ticket, type, bpc, len, sums_out, sums_cap);
 }
 
-static int finish(ozcs_pipe* p, int ticket, uint64_t* n_sums, bool block) {
-  if (!p) return fail(OZCS_EINVAL, "null pipe");
-  std::unique_lock<std::mutex> lk(p->mu);
-  if (ticket < 0 || (size_t)ticket >= p->slots.size()) return fail(OZCS_EINVAL, "bad ticket %d", ticket);
-  Slot& s = p->slots[ticket];
-  if (s.state == kAcquired) return fail(OZCS_EINVAL, "ticket %d was never submitted", ticket);
-  if (s.state == kInFlight) {
-    DeviceGuard dg(p->device);
-    if (s.deferred) (void)flush_deferred(p);
-    hipError_t e = query_event(s.done);
-    if (e == hipErrorNotReady && block) {
-      // wait without the pipe's lock, so that other threads keep submitting meanwhile; only the ticket's
-      // holder or ozcs_pipe_drain can complete this slot, and drain leaves the same result behind
-      hipEvent_t done = s.done;
-      lk.unlock();
-      e = hipEventSynchronize(done);
-      lk.lock();
-      if (s.state != kInFlight) {  // drained by another thread while this one waited
-        if (n_sums) *n_sums = s.n_sums;
-        return s.status;
-      }
-    }
-    if (e == hipErrorNotReady) return OZCS_EBUSY;
-    if (e != hipSuccess) {
-      s.status = OZCS_EHIP;
-      s.state = kFree;
-      return fail_hip(e, "pipe completion");
-    }
-    retire(s);
-  }
-  if (n_sums) *n_sums = s.n_sums;
-  return s.status;
-}
-
 int ozcs_pipe_poll(ozcs_pipe* p, int ticket, uint64_t* n_sums) { return finish(p, ticket, n_sums, false); }
 int ozcs_pipe_wait(ozcs_pipe* p, int ticket, uint64_t* n_sums) { return finish(p, ticket, n_sums, true); }
 
+int ozcs_pipe_next_completed(ozcs_pipe* p, int block, int* ticket, int* status, uint64_t* n_sums) {
+  if (!p || !ticket) return fail(OZCS_EINVAL, "null argument");
+  std::unique_lock<std::mutex> lk(p->mu);
+  DeviceGuard dg(p->device);
+  for (;;) {
+    reap(p);
+    if (!p->deferred.empty()) (void)launch_deferred(p);
+    if (p->done_unclaimed) {
+      for (size_t i = 0; i < p->slots.size(); i++) {
+        Slot& s = p->slots[i];
+        if (s.state != kDone) continue;
+        *ticket = make_ticket((int)i, s.epoch);
+        if (status) *status = s.status;
+        if (n_sums) *n_sums = s.n_sums;
+        retire(p, s);
+        return OZCS_OK;
+      }
+    }
+    if (p->in_flight == 0) return fail(OZCS_EEMPTY, "no submitted ticket is outstanding");
+    if (!block) return OZCS_EBUSY;
+    hipEvent_t ev = progress_event(p, nullptr);
+    if (!ev) return fail(OZCS_EHIP, "tickets are in flight but no GPU work is queued");
+    lk.unlock();
+    const hipError_t e = hipEventSynchronize(ev);
+    lk.lock();
+    if (e != hipSuccess) return fail_hip(e, "pipe completion");
+  }
+}
+
 int ozcs_pipe_drain(ozcs_pipe* p) {
   if (!p) return fail(OZCS_EINVAL, "null pipe");
-  std::lock_guard<std::mutex> lk(p->mu);
+  std::unique_lock<std::mutex> lk(p->mu);
   DeviceGuard dg(p->device);
-  int rc = flush_deferred(p);
-  for (Slot& s : p->slots) {
-    if (s.state != kInFlight) continue;
-    hipError_t e = hipEventSynchronize(s.done);
-    if (e != hipSuccess) {
-      s.status = OZCS_EHIP;
-      s.state = kFree;
-      rc = fail_hip(e, "pipe drain");
-    } else {
-      retire(s);
+  int rc = OZCS_OK;
+  for (;;) {
+    reap(p);
+    if (!p->deferred.empty()) (void)launch_deferred(p);
+    for (Slot& s : p->slots) {
+      if (s.state != kDone) continue;
+      if (s.status != OZCS_OK && rc == OZCS_OK) rc = s.status;
+      retire(p, s);
     }
+    if (p->in_flight == 0) return rc;
+    hipEvent_t ev = progress_event(p, nullptr);
+    if (!ev) return fail(OZCS_EHIP, "tickets are in flight but no GPU work is queued");
+    lk.unlock();
+    const hipError_t e = hipEventSynchronize(ev);
+    lk.lock();
+    if (e != hipSuccess) return fail_hip(e, "pipe drain");
   }
-  return rc;
 }
 
 }  // extern "C"

@@ -156,8 +156,8 @@ class PinnedChunkPool {
   void writeChunk(int ticket, uint64_t len) {
     const int t = (int)type_;
     const uint64_t n = type_ == ChecksumType::NONE ? 0 : ozcs_num_checksums(len, (uint32_t)bpc_);
-    outs_.at((size_t)ticket).assign((size_t)(n * ozcs_digest_size(t)), '\0');
-    std::string& o = outs_[(size_t)ticket];
+    std::string& o = outs_.at((size_t)ozcs_pipe_ticket_slot(ticket));
+    o.assign((size_t)(n * ozcs_digest_size(t)), '\0');
     const int rc = ozcs_pipe_submit_slot(pipe_, ticket, t, (uint32_t)bpc_, len, o.empty() ? nullptr : &o[0], o.size());
     if (rc == OZCS_EINVAL && (t < OZCS_NONE || t > OZCS_MD5)) throw OzoneChecksumException(type_);
     if (rc != OZCS_OK) throw GpuUnavailable(rc, std::string("ozcs_pipe_submit_slot: ") + ozcs_last_error());
@@ -168,7 +168,7 @@ class PinnedChunkPool {
     uint64_t n = 0;
     const int rc = ozcs_pipe_wait(pipe_, ticket, &n);
     if (rc != OZCS_OK) throw GpuUnavailable(rc, std::string("ozcs_pipe_wait: ") + ozcs_last_error());
-    const std::string& raw = outs_.at((size_t)ticket);
+    const std::string& raw = outs_.at((size_t)ozcs_pipe_ticket_slot(ticket));
     const size_t ds = ozcs_digest_size((int)type_);
     std::vector<ByteString> v;
     for (uint64_t i = 0; i < n; i++) v.emplace_back(raw.substr((size_t)i * ds, ds));
@@ -179,7 +179,7 @@ class PinnedChunkPool {
   ozcs_pipe* pipe_ = nullptr;
   ChecksumType type_;
   int bpc_;
-  std::vector<std::string> outs_;  // per ticket: where the pipe delivers the digests
+  std::vector<std::string> outs_;  // per slot: where the pipe delivers the digests of the slot's current ticket
 };
 
 }  // namespace ozone

@@ -74,6 +74,9 @@ SIGNATURES = {
     "ozcs_pipe_poll": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]),
     "ozcs_pipe_wait": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]),
     "ozcs_pipe_drain": (ctypes.c_int, [ctypes.c_void_p]),
+    "ozcs_pipe_ticket_slot": (ctypes.c_int, [ctypes.c_int]),
+    "ozcs_pipe_next_completed": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
+                                                ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64)]),
 }
 
 

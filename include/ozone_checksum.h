@@ -59,7 +59,8 @@ enum ozcs_status {
   OZCS_ENOMEM = -4,   /* host or device allocation failed */
   OZCS_ERANGE = -5,   /* verify: start_index + computed count exceeds the stored list
                          (ChecksumData.java:142-147) */
-  OZCS_EEMPTY = -6,   /* verify: stored or computed list is empty (ChecksumData.java:121-129) */
+  OZCS_EEMPTY = -6,   /* verify: stored or computed list is empty (ChecksumData.java:121-129);
+                         ozcs_pipe_next_completed: nothing is outstanding */
   OZCS_EBUSY = -7     /* pipeline: no free slot */
 };
 
@@ -186,25 +187,34 @@ OZCS_API int ozcs_verify_device_noalloc(int device, int type, uint32_t bpc, cons
 /* ---- asynchronous pinned pipeline: host buffer -> GPU -> digests back on the host ----
  * The write path of BlockOutputStream (BlockOutputStream.java:495-507, 645-690) fills one chunk buffer while
  * the previous one is checksummed and shipped.  A pipe gives that overlap across the PCIe link: n_slots
- * pinned chunk buffers (taking the place of BufferPool's heap buffers, BufferPool.java:74-85), and three
- * HIP streams chained by events: host-to-device copy of chunk n+1, kernel of chunk n and digest copy-back
- * of chunk n-1 run concurrently.  Mixed checksum types per chunk are allowed.
- * A pipe may be shared by threads (calls are serialised inside); tickets are slot numbers. */
+ * pinned chunk buffers (taking the place of BufferPool's heap buffers, BufferPool.java:74-85); the
+ * host-to-device copy of chunk n+1 runs while the kernel of chunk n does, and kernels write their digests
+ * straight into pinned host memory.  Mixed checksum types per chunk are allowed: CRC chunks complete in
+ * submission order; SHA-256 / MD5 chunks are hashed in batches on streams of their own (several batches at a
+ * time), never in front of a CRC chunk, and complete when their batch does.
+ * A pipe may be shared by threads (calls are serialised inside).  A ticket is a non-negative int that names one
+ * tenancy of one slot (slot number in its low 12 bits, see ozcs_pipe_ticket_slot); it ends when the ticket has
+ * been polled to completion, waited for, handed out by ozcs_pipe_next_completed or drained -- whichever comes
+ * first; the others then report the same outcome. */
 
 typedef struct ozcs_pipe ozcs_pipe;
 
+/* n_slots <= 4096. */
 OZCS_API int ozcs_pipe_create(int device, uint32_t n_slots, uint64_t slot_bytes, ozcs_pipe** out);
 OZCS_API void ozcs_pipe_destroy(ozcs_pipe* pipe);
 /* Capacity of every slot buffer of the pipe in bytes (the slot_bytes it was created with); 0 for NULL.
  * A binding that wraps a slot in a bounded buffer object (a direct ByteBuffer) sizes it with this. */
 OZCS_API uint64_t ozcs_pipe_slot_bytes(const ozcs_pipe* pipe);
+/* The slot number (0 .. n_slots-1) a ticket belongs to, for callers that keep per-slot state; -1 for a negative
+ * ticket. */
+OZCS_API int ozcs_pipe_ticket_slot(int ticket);
 
 /* Borrow a free slot: *buf is its pinned host buffer of slot_bytes bytes for the producer to fill in place
  * (zero staging copies).  OZCS_EBUSY when no slot is free: a submitted slot stays its ticket's until that
- * ticket has been polled to completion, waited for or drained. */
+ * ticket's tenancy has ended. */
 OZCS_API int ozcs_pipe_acquire(ozcs_pipe* pipe, void** buf, int* ticket);
-/* Queue copy + checksum + copy-back for the first `len` bytes of an acquired slot.  sums_out (host, any
- * memory) receives the digests when the ticket completes. */
+/* Queue copy + checksum for the first `len` bytes of an acquired slot.  sums_out (host, any memory) receives
+ * the digests when the ticket completes.  A rejected submission (OZCS_EINVAL ...) releases the slot. */
 OZCS_API int ozcs_pipe_submit_slot(ozcs_pipe* pipe, int ticket, int type, uint32_t bpc, uint64_t len,
                                    void* sums_out, uint64_t sums_cap);
 /* Convenience for callers that already hold the chunk elsewhere (e.g. a heap byte[] pinned through
@@ -215,7 +225,15 @@ OZCS_API int ozcs_pipe_submit(ozcs_pipe* pipe, int type, uint32_t bpc, const voi
 OZCS_API int ozcs_pipe_poll(ozcs_pipe* pipe, int ticket, uint64_t* n_sums);
 /* Blocks until the ticket completes. */
 OZCS_API int ozcs_pipe_wait(ozcs_pipe* pipe, int ticket, uint64_t* n_sums);
-/* Blocks until every submitted ticket has completed (their slots are freed). */
+/* Hands out any one completed ticket (its digests are in its sums_out, its slot is free again): the way many
+ * streams that share one pipe -- or one stream whose chunks may complete out of order -- keep every slot
+ * busy without waiting for a particular ticket.  Returns OZCS_OK with *ticket, *status (that ticket's own
+ * OZCS_* outcome) and *n_sums set; OZCS_EBUSY when tickets are in flight but none has completed yet (only
+ * with block == 0; with block != 0 the call waits for one); OZCS_EEMPTY when no submitted ticket is
+ * outstanding.  status and n_sums may be NULL. */
+OZCS_API int ozcs_pipe_next_completed(ozcs_pipe* pipe, int block, int* ticket, int* status, uint64_t* n_sums);
+/* Blocks until every submitted ticket has completed (their slots are freed).  Returns the first failure among
+ * them, or OZCS_OK. */
 OZCS_API int ozcs_pipe_drain(ozcs_pipe* pipe);
 
 /* ---- counters (no counterpart in the reference, which has no checksum-throughput metric) ---- */

@@ -1,0 +1,172 @@
+"""The pinned pipeline beyond the basic flow: completion in any order, ticket tenancies under concurrent
+ozcs_pipe_drain, and a refused digest launch.  Digests are compared with the CPU oracle (bit-exact)."""
+import ctypes
+import os
+import subprocess
+import sys
+import threading
+import time
+
+import pytest
+
+import oracle
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+MIB = 1 << 20
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch  # before the library: both then share one HIP runtime
+    from hadoop_ozone_amd import native
+    assert torch.cuda.is_available()
+    L = native.lib()
+    native.check(L.ozcs_init(0))
+    torch.cuda.set_device(0)
+    return torch, native, L
+
+
+def test_pipe_next_completed_any_order(gpu):
+    # many streams sharing one pipe: chunks are harvested as they complete, CRC chunks overtake MD5 chunks
+    # submitted before them (a 1 MiB MD5 window keeps one lane busy for milliseconds)
+    torch, native, L = gpu
+    pipe = ctypes.c_void_p()
+    native.check(L.ozcs_pipe_create(0, 8, 4 * MIB, ctypes.byref(pipe)))
+    try:
+        ticket, status, n = ctypes.c_int(-1), ctypes.c_int(99), ctypes.c_uint64()
+        assert L.ozcs_pipe_next_completed(pipe, 0, ctypes.byref(ticket), ctypes.byref(status), ctypes.byref(n)) == native.EEMPTY
+        assert L.ozcs_pipe_next_completed(pipe, 1, ctypes.byref(ticket), None, None) == native.EEMPTY
+        jobs, order, submitted = {}, [], 0
+        total = 48
+
+        def harvest(block):
+            rc = L.ozcs_pipe_next_completed(pipe, block, ctypes.byref(ticket), ctypes.byref(status), ctypes.byref(n))
+            if rc == native.EBUSY:
+                return False
+            native.check(rc)
+            j = jobs.pop(ticket.value)
+            assert status.value == native.OK
+            assert 0 <= L.ozcs_pipe_ticket_slot(ticket.value) < 8
+            exp = oracle.compute(j["t"], j["bpc"], j["d"])
+            assert n.value * native.DIGEST_SIZE[j["t"]] == len(exp)
+            assert j["out"].raw[:len(exp)] == exp, j["i"]
+            order.append(j["i"])
+            return True
+
+        while submitted < total:
+            i = submitted
+            t = (oracle.MD5, oracle.CRC32, oracle.CRC32C, oracle.SHA256)[i % 4] if i % 8 < 4 else oracle.CRC32
+            bpc = MIB if i % 3 else 65536
+            ln = 4 * MIB - 1000 * (i % 5)
+            d = oracle.splitmix64(7000 + i, ln)
+            out = ctypes.create_string_buffer(((ln + bpc - 1) // bpc) * native.DIGEST_SIZE[t])
+            tk = ctypes.c_int(-1)
+            rc = L.ozcs_pipe_submit(pipe, t, bpc, d.ctypes.data, ln, out, len(out), ctypes.byref(tk))
+            if rc == native.EBUSY:
+                assert harvest(1)
+                continue
+            native.check(rc)
+            assert tk.value not in jobs
+            jobs[tk.value] = {"t": t, "bpc": bpc, "d": d, "out": out, "i": i}
+            submitted += 1
+            harvest(0)
+        while jobs:
+            assert harvest(1)
+        assert sorted(order) == list(range(total))
+        assert order != list(range(total)), "every chunk completed in submission order: digest batches block CRC chunks"
+        assert L.ozcs_pipe_next_completed(pipe, 1, ctypes.byref(ticket), None, None) == native.EEMPTY
+    finally:
+        L.ozcs_pipe_destroy(pipe)
+
+
+def test_pipe_ticket_names_one_tenancy(gpu):
+    torch, native, L = gpu
+    pipe = ctypes.c_void_p()
+    native.check(L.ozcs_pipe_create(0, 1, MIB, ctypes.byref(pipe)))
+    try:
+        d = oracle.splitmix64(1, MIB)
+        out = ctypes.create_string_buffer(64)
+        t1, t2, n = ctypes.c_int(), ctypes.c_int(), ctypes.c_uint64(77)
+        native.check(L.ozcs_pipe_submit(pipe, oracle.CRC32, 65536, d.ctypes.data, MIB, out, 64, ctypes.byref(t1)))
+        native.check(L.ozcs_pipe_drain(pipe))   # ends the tenancy behind the holder's back
+        assert out.raw == oracle.compute(oracle.CRC32, 65536, d)
+        native.check(L.ozcs_pipe_wait(pipe, t1.value, ctypes.byref(n)))   # ... and the holder still learns the outcome
+        assert n.value == 16
+        native.check(L.ozcs_pipe_poll(pipe, t1.value, None))
+        # the slot is let again: a different ticket, and the old one does not touch the new tenancy
+        out2 = ctypes.create_string_buffer(b"\xEE" * 16, 16)
+        native.check(L.ozcs_pipe_submit(pipe, oracle.MD5, MIB, d.ctypes.data, MIB, out2, 16, ctypes.byref(t2)))
+        assert t2.value != t1.value and L.ozcs_pipe_ticket_slot(t2.value) == L.ozcs_pipe_ticket_slot(t1.value) == 0
+        native.check(L.ozcs_pipe_wait(pipe, t1.value, ctypes.byref(n)))   # still the recorded outcome of tenancy 1
+        assert n.value == 16
+        native.check(L.ozcs_pipe_wait(pipe, t2.value, ctypes.byref(n)))
+        assert n.value == 1 and out2.raw == oracle.compute(oracle.MD5, MIB, d)
+        assert L.ozcs_pipe_poll(pipe, t1.value, None) == native.EINVAL   # only the last ended tenancy is on record
+        assert L.ozcs_pipe_poll(pipe, 12345678, None) == native.EINVAL
+        assert L.ozcs_pipe_poll(pipe, -1, None) == native.EINVAL
+        assert L.ozcs_pipe_ticket_slot(-5) == -1
+    finally:
+        L.ozcs_pipe_destroy(pipe)
+
+
+def test_pipe_waiters_against_concurrent_drain(gpu):
+    # producers wait for their own tickets while another thread keeps draining the pipe: a waiter that lost the
+    # lock must never complete (or read the digests of) a later tenancy of its slot
+    torch, native, L = gpu
+    pipe = ctypes.c_void_p()
+    native.check(L.ozcs_pipe_create(0, 3, MIB, ctypes.byref(pipe)))
+    errors, stop = [], threading.Event()
+
+    def producer(k):
+        try:
+            for i in range(40):
+                t = (oracle.CRC32C, oracle.MD5, oracle.CRC32, oracle.SHA256)[(i + k) % 4]
+                ln = MIB - 41 * i - k
+                bpc = 262144 if i % 2 else 16384
+                d = oracle.splitmix64(9000 + 100 * k + i, ln)
+                out = ctypes.create_string_buffer(((ln + bpc - 1) // bpc) * native.DIGEST_SIZE[t])
+                ticket = ctypes.c_int(-1)
+                while True:
+                    rc = L.ozcs_pipe_submit(pipe, t, bpc, d.ctypes.data, ln, out, len(out), ctypes.byref(ticket))
+                    if rc != native.EBUSY:
+                        break
+                    time.sleep(0.0002)
+                native.check(rc)
+                n = ctypes.c_uint64()
+                native.check(L.ozcs_pipe_wait(pipe, ticket.value, ctypes.byref(n)))
+                assert n.value == (ln + bpc - 1) // bpc
+                assert out.raw == oracle.compute(t, bpc, d), (k, i)
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    def drainer():
+        try:
+            while not stop.is_set():
+                native.check(L.ozcs_pipe_drain(pipe))
+        except Exception as e:   # noqa: BLE001
+            errors.append("drainer: " + repr(e))
+
+    try:
+        ts = [threading.Thread(target=producer, args=(k,)) for k in range(4)]
+        dr = threading.Thread(target=drainer)
+        dr.start()
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        stop.set()
+        dr.join()
+        assert not errors, errors
+    finally:
+        L.ozcs_pipe_destroy(pipe)
+
+
+def test_pipe_refused_digest_launch_is_reported_by_its_tickets(gpu):
+    e = dict(os.environ)
+    e["OZCS_FAULT_PIPE_DIGEST_LAUNCH"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "pipe_fault_check.py")], env=e, capture_output=True,
+                       text=True, timeout=110)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "pipe fault check ok" in r.stdout
