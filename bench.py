@@ -24,7 +24,17 @@ MIB = 1 << 20
 BLOCK_BYTES = 256 * MIB   # ozone.scm.block.size, OzoneConfigKeys.java:115-116
 CHUNK_BYTES = 4 * MIB     # ozone.scm.chunk.size / stream buffer, OzoneClientConfig.java:50-55
 HBM_PEAK_GBPS = 8000.0    # MI355X HBM3E datasheet peak
-MEASURED_NT_READ_GBPS = 7070.0  # pure non-temporal streaming read in the kernel's access pattern (profiles/r01_hbm_read_microbench.log)
+# Recorded constant, not measured in this run: a pure non-temporal streaming read in the CRC kernel's access
+# pattern on MI355X (tools/hbm_read_bench.hip).
+RECORDED_NT_READ = {"GBps": 7070.0, "source": "profiles/r01_hbm_read_microbench.log", "measured_in_this_run": False}
+# Integer-VALU ceiling of the chip for SHA-256 / MD5: 256 CUs x 4 SIMDs, one wave64 vector instruction per
+# 4 cycles per SIMD, at the 2.4 GHz maximum clock.
+SIMDS = 256 * 4
+MAX_CLOCK_HZ = 2.4e9
+VALU_PEAK_GINSTR = SIMDS * MAX_CLOCK_HZ / 4 / 1e9   # 614.4 G wave-instructions/s
+# Vector instructions one lane executes per 64-byte block in the one-wavefront kernels (counted in the ISA of
+# digest_kernels.hip's check-free loop; SQ_INSTS_VALU per block in profiles/pmc_summary.json when present).
+ISA_VALU_PER_BLOCK = {"SHA256": 1404, "MD5": 351}
 
 
 def shard_blocks(total_blocks, rank, world):
@@ -40,16 +50,38 @@ def aggregate(bytes_per_rank_step, steps, max_elapsed_s, world):
     return total / max_elapsed_s / 1e9
 
 
-def load_profile_traffic(workload):
-    """HBM bytes per launch measured by the committed rocprofv3 PMC passes, if they cover this workload."""
+def load_profile(workload, source_hash):
+    """The committed rocprofv3 PMC record of this workload (profiles/pmc_summary.json), or (None, why): a record
+    counts only when it was taken from the very sources the loaded library was built from."""
     path = os.path.join(ROOT, "profiles", "pmc_summary.json")
     try:
         with open(path) as f:
-            rec = json.load(f)
-        ent = rec.get(workload)
-        return ent.get("hbm_bytes_per_launch") if ent else None
+            ent = json.load(f).get(workload)
     except (OSError, ValueError):
-        return None
+        return None, "profiles/pmc_summary.json is missing or unreadable"
+    if not ent:
+        return None, "no PMC record for workload %s" % workload
+    if ent.get("source_hash") != source_hash:
+        return None, "PMC record of %s was taken from other kernel sources (%s, now %s): re-profile" % (
+            workload, ent.get("source_hash"), source_hash)
+    return ent, None
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the ranks as a child process (before this process
+    touches the GPU), relay its output and exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env)
+    sys.exit(r.returncode)
 
 
 def cpu_baseline(sample, bpc):
@@ -99,6 +131,9 @@ def main():
     ap.add_argument("--device-index", type=int, default=-1, help="GPU of this rank (default: LOCAL_RANK)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)
+
     import torch
     import torch.distributed as dist
     from hadoop_ozone_amd import native
@@ -107,8 +142,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        sys.exit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (there is no CPU path in this library)")
     if args.device_index >= 0:
@@ -189,6 +223,8 @@ def main():
         achieved = alg_bytes / avg_kernel_s / 1e9
         workload = "%s %s, %d x 256 MiB blocks per GPU (4 MiB chunks, %d B windows), device-resident" % (
             args.type, args.mode, args.blocks, args.bpc)
+        src_hash = native.source_hash()
+        prof, prof_note = load_profile("%s-%d-%d" % (args.type, args.bpc, args.blocks), src_hash)
         out = {
             "metric": "device-resident checksum GB/s (%s, %s bytes/checksum)" % (
                 args.type, "1MB" if args.bpc == MIB else str(args.bpc)),
@@ -198,15 +234,40 @@ def main():
             "config": {"workload": workload, "blocks_per_gpu": args.blocks, "chunk_bytes": CHUNK_BYTES,
                        "bytes_per_checksum": args.bpc, "windows_per_gpu": n_windows, "sharding": "by block, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "peak_measured_nt_read": MEASURED_NT_READ_GBPS,
                          "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "traffic": load_profile_traffic("%s-%d-%d" % (args.type, args.bpc, args.blocks)),
+                         "traffic": prof.get("hbm_bytes_per_launch") if prof else None,
                          "kernel_ms_avg": round(avg_kernel_s * 1e3, 4), "kernel_ms_min": round(min(kernel_ms), 4),
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "kernel_source_hash": src_hash,
+                         "recorded_nt_read_ceiling": RECORDED_NT_READ},
         }
+        if prof_note:
+            out["roofline"]["traffic_note"] = prof_note
         if args.type in ("SHA256", "MD5"):
-            out["roofline"]["note"] = ("integer-VALU bound (one lane per window, ~22 / ~5 vector instructions per byte); "
-                                       "the HBM fraction is reported because the metric asks for it")
+            # The bound that matters for the digests: vector-instruction issue.  One lane hashes one window, 64 windows
+            # per wavefront; a window of w bytes is (w + 8) // 64 + 1 blocks (data + padding).
+            full, tail = divmod(CHUNK_BYTES, args.bpc)
+            blocks = n_chunks * (full * ((args.bpc + 8) // 64 + 1) + ((tail + 8) // 64 + 1 if tail else 0))
+            per_block = ISA_VALU_PER_BLOCK[args.type]
+            source = "ISA count of the one-wavefront loop"
+            if prof and prof.get("valu_per_block_lane"):
+                per_block, source = prof["valu_per_block_lane"], "SQ_INSTS_VALU per block (profiles/pmc_summary.json)"
+            ginstr = blocks * per_block / 64 / avg_kernel_s / 1e9
+            hbm = out["roofline"]
+            out["roofline"] = {
+                "bound": "valu", "achieved": round(ginstr, 2), "peak": round(VALU_PEAK_GINSTR, 1),
+                "unit": "G wave64-instr/s", "frac": round(ginstr / VALU_PEAK_GINSTR, 4), "traffic": hbm["traffic"],
+                "valu_per_block_lane": per_block, "valu_per_block_source": source, "blocks_per_launch": blocks,
+                "peak_is": "%d SIMDs x %.1f GHz / 4 cycles per wave64 vector instruction" % (SIMDS, MAX_CLOCK_HZ / 1e9),
+                "kernel_ms_avg": hbm["kernel_ms_avg"], "kernel_ms_min": hbm["kernel_ms_min"],
+                "kernel_source_hash": src_hash,
+                "hbm": {"achieved": hbm["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm["frac"],
+                        "algorithmic_bytes_per_launch": alg_bytes},
+                "note": "one lane per window: integer-VALU issue bounds SHA-256 / MD5, not HBM; the HBM fraction is kept "
+                        "as a secondary figure because the metric is quoted in GB/s",
+            }
+            if prof_note:
+                out["roofline"]["traffic_note"] = prof_note
         if world == 1 and not args.no_cpu_baseline and args.type == "CRC32" and args.mode == "compute":
             sample = data[: min(nbytes, 2 << 30)].cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(sample, args.bpc)

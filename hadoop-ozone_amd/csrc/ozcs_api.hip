@@ -575,6 +575,27 @@ uint64_t ozcs_num_checksums(uint64_t len, uint32_t bpc) {
   return len / bpc + (len % bpc ? 1 : 0);
 }
 
+void ozcs_shard_chunks(const ozcs_chunk* chunks, uint32_t n_chunks, uint32_t n_parts, uint32_t* cuts) {
+  if (!cuts || n_parts == 0) return;
+  uint64_t total = 0;
+  for (uint32_t i = 0; chunks && i < n_chunks; i++) total += chunks[i].len;
+  cuts[0] = 0;
+  uint32_t i = 0;
+  uint64_t before = 0;  // bytes of chunks [0, i)
+  for (uint32_t d = 1; d < n_parts; d++) {
+    // part d starts at the first chunk whose predecessors hold at least d/n_parts of the bytes; a list without
+    // bytes (all chunks empty) is split by count
+    if (total == 0) {
+      i = (uint32_t)((uint64_t)n_chunks * d / n_parts);
+    } else {
+      const unsigned __int128 target = (unsigned __int128)total * d;
+      while (i < n_chunks && (unsigned __int128)before * n_parts < target) before += chunks[i++].len;
+    }
+    cuts[d] = i;
+  }
+  cuts[n_parts] = n_chunks;
+}
+
 int ozcs_init(uint32_t device_mask) {
   Global& g = global();
   std::lock_guard<std::mutex> lk(g.init_mu);
@@ -841,18 +862,42 @@ int ozcs_compute_batch(ozcs_chunk* chunks, uint32_t n_chunks) try {
   if (ndev == 1 || n_chunks == 1) {
     batch_on_device(g.devs[0].id, chunks, 0, n_chunks);
   } else {
-    // contiguous shards of the chunk list, one host thread per device, no inter-device traffic
-    std::vector<std::thread> th;
-    for (size_t d = 0; d < ndev; d++) {
-      const uint32_t lo = (uint32_t)((uint64_t)n_chunks * d / ndev), hi = (uint32_t)((uint64_t)n_chunks * (d + 1) / ndev);
-      if (lo >= hi) continue;
+    // contiguous shards of the chunk list with about equal bytes, one host thread per device, no inter-device
+    // traffic.  A worker keeps its failure text (the error text is per thread) and lets no exception escape.
+    std::vector<uint32_t> cuts(ndev + 1);
+    ozcs_shard_chunks(chunks, n_chunks, (uint32_t)ndev, cuts.data());
+    std::vector<std::string> msgs(ndev);
+    auto work = [&](size_t d) {
+      const uint32_t lo = cuts[d], hi = cuts[d + 1];
       try {
-        th.emplace_back(batch_on_device, g.devs[d].id, chunks, lo, hi);
-      } catch (...) {  // no thread to be had: the caller's thread serves that device's share
+        t_err.clear();
         batch_on_device(g.devs[d].id, chunks, lo, hi);
+        msgs[d] = t_err;
+      } catch (...) {  // std::bad_alloc from the staging lists
+        for (uint32_t i = lo; i < hi; i++) { chunks[i].status = OZCS_ENOMEM; chunks[i].n_sums = 0; }
+        msgs[d] = "out of host memory in ozcs_compute_batch";
+      }
+    };
+    std::vector<std::thread> th;
+    std::vector<size_t> inline_shards;
+    for (size_t d = 1; d < ndev; d++) {
+      if (cuts[d] >= cuts[d + 1]) continue;
+      try {
+        th.emplace_back(work, d);
+      } catch (...) {  // no thread to be had: the caller's thread serves that device's share
+        inline_shards.push_back(d);
       }
     }
+    const std::string callers = t_err;
+    if (cuts[0] < cuts[1]) work(0);
+    for (size_t d : inline_shards) work(d);
     for (auto& t : th) t.join();
+    t_err = callers;
+    for (size_t d = 0; d < ndev; d++) {
+      bool failed = false;
+      for (uint32_t i = cuts[d]; i < cuts[d + 1] && !failed; i++) failed = chunks[i].status != OZCS_OK;
+      if (failed) { t_err = msgs[d]; break; }
+    }
   }
   for (uint32_t i = 0; i < n_chunks; i++)
     if (chunks[i].status != OZCS_OK) return chunks[i].status;

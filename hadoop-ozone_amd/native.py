@@ -50,6 +50,8 @@ SIGNATURES = {
                                    ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64,
                                    ctypes.POINTER(ctypes.c_int64)]),
     "ozcs_compute_batch": (ctypes.c_int, [ctypes.POINTER(OzcsChunk), ctypes.c_uint32]),
+    "ozcs_shard_chunks": (None, [ctypes.POINTER(OzcsChunk), ctypes.c_uint32, ctypes.c_uint32,
+                                 ctypes.POINTER(ctypes.c_uint32)]),
     "ozcs_verify_batch": (ctypes.c_int, [ctypes.POINTER(OzcsVChunk), ctypes.c_uint32]),
     "ozcs_compute_device": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p,
                                            ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p,
@@ -86,6 +88,21 @@ def build(force=False):
         subprocess.check_call(["make", "-s", "-C", CSRC, "clean"])
     subprocess.check_call(["make", "-s", "-j8", "-C", CSRC, "libozcs.so"])
     return LIB_PATH
+
+
+def source_hash():
+    """SHA-256 over the library's sources (csrc/*.hip, csrc/*.h, the ABI header), the stamp that ties a
+    committed profile to the kernels it was taken from."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")))
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "ozone_checksum.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 _lib = None

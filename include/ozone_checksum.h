@@ -117,12 +117,18 @@ typedef struct ozcs_chunk {
 
 /* The loop of BlockOutputStream.writeChunkToContainer (BlockOutputStream.java:645-656) over many
  * chunks at once.  Chunks are sharded contiguously over the initialised devices (chunk list, not
- * windows); there is no inter-device traffic.  Chunks of any sizes and types may be mixed: small ones (small
+ * windows; about equal bytes per device, see ozcs_shard_chunks); there is no inter-device traffic.  Chunks of any sizes and types may be mixed: small ones (small
  * keys, tail chunks) are gathered and served by one kernel launch per checksum type, so the cost per small
  * chunk is well under a microsecond rather than a copy and a launch each.  A call in flight holds up to
  * 512 MiB of pinned host memory and as much device memory (kept for the next call of the same thread pool
  * slot, released by ozcs_shutdown).  Returns the first non-OK per-chunk status, or OZCS_OK. */
 OZCS_API int ozcs_compute_batch(ozcs_chunk* chunks, uint32_t n_chunks);
+
+/* The partition ozcs_compute_batch uses to spread a chunk list over n_parts devices (pure function, no GPU
+ * needed): contiguous parts of about equal bytes, so that a list of mixed chunk sizes loads the devices evenly.
+ * cuts must hold n_parts + 1 entries; part d is chunks [cuts[d], cuts[d+1]), cuts[0] = 0, cuts[n_parts] =
+ * n_chunks; parts may be empty.  No counterpart in the reference, whose callers checksum one chunk at a time. */
+OZCS_API void ozcs_shard_chunks(const ozcs_chunk* chunks, uint32_t n_chunks, uint32_t n_parts, uint32_t* cuts);
 
 typedef struct ozcs_vchunk {
   const void* data;        /* in : host pointer of the bytes read                                 */

@@ -543,16 +543,20 @@ def test_bench_two_ranks_rehearsal(gpu):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--blocks", "2", "--dist-backend", "gloo", "--device-index", "0"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=170, cwd=ROOT)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1   # rank 0 alone prints
-    rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0 and "cpu_baseline" not in rec
-    assert rec["config"]["blocks_per_gpu"] == 2
+    tail = ["--gpus", "2", "--steps", "3", "--warmup", "1", "--blocks", "2", "--dist-backend", "gloo", "--device-index", "0"]
+    launched = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py")] + tail
+    # ... and the bare form, in which bench.py starts its two ranks itself (as a child, before any GPU call)
+    bare = [sys.executable, os.path.join(ROOT, "bench.py")] + tail
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    for cmd in (launched, bare):
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=170, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1   # rank 0 alone prints
+        rec = json.loads(lines[0])
+        assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0 and "cpu_baseline" not in rec
+        assert rec["config"]["blocks_per_gpu"] == 2
 
 
 def test_stats_counters_and_pipe_slot_bytes(gpu):

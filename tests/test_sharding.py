@@ -60,3 +60,56 @@ def test_two_ranks_shard_by_chunk(tmp_path):
     exp = b"".join(oracle.compute(oracle.CRC32, bpc, oracle.splitmix64(1000 + c, chunk_len)) for c in range(n_chunks))
     assert got == exp
     assert float(np.load(str(tmp_path / "elapsed.npy"))[0]) == 1.5
+
+
+def _cuts(lens, parts):
+    import ctypes
+    from hadoop_ozone_amd import native
+    L = native.lib()   # pure function: no GPU call is made
+    arr = (native.OzcsChunk * max(1, len(lens)))()
+    for i, n in enumerate(lens):
+        arr[i].len = n
+    cuts = (ctypes.c_uint32 * (parts + 1))()
+    L.ozcs_shard_chunks(arr, len(lens), parts, cuts)
+    return list(cuts)
+
+
+def test_batch_is_sharded_over_devices_by_bytes():
+    # equal chunks: equal counts
+    assert _cuts([4 << 20] * 8, 4) == [0, 2, 4, 6, 8]
+    assert _cuts([4 << 20] * 64, 8) == list(range(0, 65, 8))
+    # one large chunk in front: it gets a device to itself, the small ones share the other
+    assert _cuts([64 << 20] + [1 << 20] * 64, 2) == [0, 1, 65]
+    # mixed sizes: every part within one chunk of its byte share, parts contiguous and complete
+    rng = np.random.default_rng(3)
+    for parts in (2, 3, 8):
+        lens = [int(x) for x in rng.integers(1, 8 << 20, 300)]
+        cuts = _cuts(lens, parts)
+        assert cuts[0] == 0 and cuts[-1] == len(lens) and all(a <= b for a, b in zip(cuts, cuts[1:]))
+        share = sum(lens) / parts
+        for d in range(parts):
+            assert abs(sum(lens[cuts[d]:cuts[d + 1]]) - share) <= max(lens)
+        by_count = [len(lens) * d // parts for d in range(parts + 1)]
+        worst = max(sum(lens[cuts[d]:cuts[d + 1]]) for d in range(parts))
+        assert worst <= max(sum(lens[by_count[d]:by_count[d + 1]]) for d in range(parts)) + max(lens)
+    # degenerate lists
+    assert _cuts([], 4) == [0, 0, 0, 0, 0]
+    assert _cuts([0, 0, 0, 0], 2) == [0, 2, 4]
+    assert _cuts([5], 3) == [0, 1, 1, 1]
+    assert _cuts([1, 1], 1) == [0, 2]
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    # `python bench.py --gpus 2` with no launcher around it: the ranks are started as a child before any GPU call.
+    # Without a GPU every rank stops at "needs a GPU"; what is checked here is that two ranks were started.
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--blocks", "1"], env=env, capture_output=True, text=True, timeout=170, cwd=str(tmp_path))
+    if torch.cuda.is_available():
+        assert r.returncode == 0, r.stderr[-2000:]
+    else:
+        assert r.returncode != 0
+        assert "bench.py needs a GPU" in r.stderr and "local_rank: 1" in r.stderr, r.stderr[-2000:]
