@@ -116,6 +116,29 @@ def cpu_baseline(sample, bpc):
     }
 
 
+def jvm_baseline(bpc, cores):
+    """The reference's production engines (java.util.zip.CRC32 / CRC32C) timed by bench/java/CrcBaseline.java, when
+    this box has a JDK; None otherwise (the build image and the project's GPU boxes have none).  Bounded: about
+    10 s of CPU work, every step under a time limit, and no failure here fails the benchmark."""
+    import shutil
+    import subprocess
+    import tempfile
+    if not (shutil.which("javac") and shutil.which("java")):
+        return None
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            subprocess.run(["javac", "-d", tmp, os.path.join(ROOT, "bench", "java", "CrcBaseline.java")], check=True,
+                           capture_output=True, timeout=120)
+            r = subprocess.run(["java", "-cp", tmp, "CrcBaseline", str(bpc), str(cores), "1.5"], check=True,
+                               capture_output=True, text=True, timeout=120)
+        for line in r.stdout.splitlines():
+            if line.startswith("{"):
+                return json.loads(line)
+    except (OSError, ValueError, subprocess.SubprocessError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -271,6 +294,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.type == "CRC32" and args.mode == "compute":
             sample = data[: min(nbytes, 2 << 30)].cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(sample, args.bpc)
+            jvm = jvm_baseline(args.bpc, out["cpu_baseline"]["cores"])
+            if jvm:   # the real thing beside the C restatement, when a JDK happens to exist
+                out["cpu_baseline"]["jvm"] = jvm
         elif world == 1:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

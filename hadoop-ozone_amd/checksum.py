@@ -22,6 +22,106 @@ class ChecksumType(enum.IntEnum):
     MD5 = 5
 
 
+OZONE_CLIENT_BYTES_PER_CHECKSUM_MIN_SIZE = 16 * 1024  # OzoneConfigKeys.java:340
+
+
+def _parse_size(v):
+    """ConfigType.SIZE values: a number with an optional B / KB / MB / GB unit (binary multiples), e.g. "1MB"."""
+    if isinstance(v, int):
+        return v
+    txt = str(v).strip().upper()
+    for suffix, mul in (("KB", 1 << 10), ("MB", 1 << 20), ("GB", 1 << 30), ("B", 1)):
+        if txt.endswith(suffix):
+            return int(float(txt[:-len(suffix)].strip()) * mul)
+    return int(txt)
+
+
+class OzoneClientConfig:
+    """The three checksum keys of the client configuration group "ozone.client" (OzoneClientConfig.java:103-125)
+    with the validation of :143-151: checksum.type defaults to CRC32, bytes.per.checksum to 1MB and is raised
+    to 16 KiB with a warning when set lower, verify.checksum defaults to true."""
+
+    PREFIX = "ozone.client"
+
+    def __init__(self, conf=None):
+        import logging
+        conf = conf or {}
+        self.checksumType = str(conf.get(self.PREFIX + ".checksum.type", ChecksumType.CRC32.name))
+        self.bytesPerChecksum = _parse_size(conf.get(self.PREFIX + ".bytes.per.checksum", "1MB"))
+        v = conf.get(self.PREFIX + ".verify.checksum", True)
+        self.checksumVerify = v if isinstance(v, bool) else str(v).strip().lower() == "true"
+        if self.bytesPerChecksum < OZONE_CLIENT_BYTES_PER_CHECKSUM_MIN_SIZE:  # :143-151
+            logging.getLogger("OzoneClientConfig").warning(
+                "The checksum size (%d) is not allowed to be less than the minimum size (%d), resetting to the "
+                "minimum size.", self.bytesPerChecksum, OZONE_CLIENT_BYTES_PER_CHECKSUM_MIN_SIZE)
+            self.bytesPerChecksum = OZONE_CLIENT_BYTES_PER_CHECKSUM_MIN_SIZE
+
+    def getChecksumType(self):
+        """ChecksumType.valueOf(checksumType) (OzoneClientConfig.java:199-201): an unknown name is an error."""
+        try:
+            return ChecksumType[self.checksumType]
+        except KeyError:
+            raise ValueError("No enum constant ChecksumType." + self.checksumType)
+
+    def setChecksumType(self, t):
+        self.checksumType = t.name
+
+    def getBytesPerChecksum(self):
+        return self.bytesPerChecksum
+
+    def setBytesPerChecksum(self, n):
+        """The setter does not clamp (OzoneClientConfig.java:207-209): only validate() does, once, after injection."""
+        self.bytesPerChecksum = n
+
+    def isChecksumVerify(self):
+        return self.checksumVerify
+
+    def setChecksumVerify(self, v):
+        self.checksumVerify = v
+
+    def newChecksum(self):
+        """What BlockOutputStream builds once per stream (BlockOutputStream.java:174-175)."""
+        return Checksum(self.getChecksumType(), self.bytesPerChecksum)
+
+
+def reference_list_windows(lengths):
+    """Which elements of a buffer list ChunkBufferImplWithByteBufferList.iterate visits, in order
+    (ChunkBufferImplWithByteBufferList.java:59-78, 192-201), given the elements' lengths.
+
+    iterate().next() calls findCurrent() every time, and findCurrent() adds the limits of the consumed buffers to
+    limitPrecedingCurrent without resetting it first.  position() = limitPrecedingCurrent + current.position()
+    therefore runs ahead of the bytes really consumed and hasRemaining() turns false early: of four equal
+    elements three are visited, of 256 only 24."""
+    n = len(lengths)
+    if n == 0:
+        return []
+    limit = sum(lengths)
+    pos = [0] * n
+    state = {"preceding": 0, "cur": 0}
+
+    def find_current():  # :59-78
+        found = False
+        for i in range(n):
+            if found:
+                continue  # (checks position == 0, which holds here)
+            if pos[i] < lengths[i]:
+                found = True
+                state["cur"] = i
+            else:
+                state["preceding"] += lengths[i]
+        if not found:
+            state["cur"] = n - 1
+            state["preceding"] -= lengths[n - 1]
+
+    find_current()  # constructor, :56
+    visited = []
+    while limit - (state["preceding"] + pos[state["cur"]]) > 0:  # hasNext(): hasRemaining()
+        find_current()
+        visited.append(state["cur"])
+        pos[state["cur"]] = lengths[state["cur"]]
+    return visited
+
+
 class OzoneChecksumException(IOError):
     """OzoneChecksumException.java:29-66 (an IOException there, so callers fail over to the next replica)."""
 
@@ -160,8 +260,13 @@ class Checksum:
         """Checksum.java:62-64: Guava Ints.toByteArray -> 4 bytes big-endian."""
         return (n & 0xFFFFFFFF).to_bytes(4, "big")
 
-    def computeChecksum(self, data, off=None, length=None):
+    def computeChecksum(self, data, off=None, length=None, reference_list_quirk=False):
         """The five computeChecksum overloads (Checksum.java:119-177).
+
+        reference_list_quirk (list inputs only): False, the default, checksums every element of the list -- the
+        documented intent (Checksum.java:279-281) and what a Checksum patched to call this library yields, since
+        the patch hands all buffers of the list to one native call.  True reproduces the unpatched reference
+        bit for bit: only the elements reference_list_windows() names are checksummed (three of four, 24 of 256).
 
         data: bytes-like (byte[] / ByteBuffer overloads; off/length as in computeChecksum(byte[],int,int)),
         or a list of bytes-like (the List<ByteString> / ChunkBuffer-of-list overloads, one element per
@@ -179,6 +284,8 @@ class Checksum:
         if bpc <= 0:
             raise ValueError("bytesPerChecksum must be positive")  # ChunkBuffer.iterate rejects it
         if isinstance(data, (list, tuple)):
+            if reference_list_quirk:
+                data = [data[i] for i in reference_list_windows([len(memoryview(b).cast("B")) for b in data])]
             return ChecksumData(ct, bpc, self._compute_list(int(ct), bpc, ds, data))
         mv = memoryview(data).cast("B") if not isinstance(data, (bytes, bytearray)) else memoryview(data)
         if off is not None:
@@ -217,8 +324,10 @@ class Checksum:
         return [o.raw for o in outs]
 
     @staticmethod
-    def verifyChecksum(data, checksumData, startIndex=0, isSingleByteString=None):
+    def verifyChecksum(data, checksumData, startIndex=0, isSingleByteString=None, reference_list_quirk=False):
         """The three verifyChecksum overloads (Checksum.java:210-290).
+
+        reference_list_quirk: as in computeChecksum, for the one-element-per-window layout (:282-288).
 
         bytes-like data: verifyChecksum(ByteString, ChecksumData, int) / (byte[], ChecksumData).
         list data + isSingleByteString: verifyChecksum(List<ByteString>, ChecksumData, int, boolean)."""
@@ -230,7 +339,7 @@ class Checksum:
             if isSingleByteString:
                 data = data[0]  # :274-277
             else:
-                computed = Checksum(t, bpc).computeChecksum(list(data))  # :282-288
+                computed = Checksum(t, bpc).computeChecksum(list(data), reference_list_quirk=reference_list_quirk)  # :282-288
                 return checksumData.verifyChecksumDataMatches(computed, startIndex)
         stored = checksumData.getChecksums()
         if len(stored) == 0:

@@ -75,10 +75,11 @@ inline std::string chunkInfoToString(const std::string& chunkName, long long off
 // One chunk of a closed container against its stored ChecksumData (KeyValueContainerCheck.java:262-322).
 // The reference reads, throttles and checks one window at a time; here the chunk's windows are read in one
 // go and checked by one ozcs_verify call.  Kept: FILE_PER_BLOCK positions the file at the chunk's offset and
-// never reads past the chunk (:276-285); the throttler sees every window's byte count in order (:294); the
-// first failing window raises the reference's text (:299-311); a file that ends early at a window boundary
+// never reads past the chunk (:276-285); window i is throttled, then judged, and the first failing window ends
+// the scan with the reference's text (:294-311), so the throttler sees exactly the windows up to the failure; a file that ends early at a window boundary
 // raises the length form (:314-320), one that ends inside a window fails that window first.
-// throttler may be empty.  Returns the number of bytes read.
+// throttler may be empty (a caller that cancels binds its canceler into it, as DataTransferThrottler.throttle(v,
+// canceler) receives it).  Returns the number of bytes read.
 inline long long verifyChunkFile(const std::string& blockId, const std::string& chunkName, long long chunkOffset,
                                  long long chunkLen, const ChecksumData& checksumData, const std::string& chunkFile,
                                  ChunkLayOutVersion layout, const std::function<void(long long)>& throttler = {}) {
@@ -97,17 +98,21 @@ inline long long verifyChunkFile(const std::string& blockId, const std::string& 
     std::fclose(f);
   }
   const long long windowsRead = bpc ? (nRead + bpc - 1) / bpc : 0;
-  if (throttler)
-    for (long long i = 0; i < windowsRead; i++) throttler(std::min(bpc, nRead - i * bpc));
   const ChecksumType type = checksumData.getChecksumType();
-  if (type != ChecksumType::NONE && windowsRead) {
+  int64_t first = -1;
+  if (type != ChecksumType::NONE && windowsRead) {  // all windows hashed and compared by one call
     std::string stored;
     for (long long i = 0; i < windowsRead; i++) stored += sums[(size_t)i];
-    const int t = (int)type;
-    int64_t first = -1;
-    const int rc = ozcs_verify(t, (uint32_t)bpc, data.data(), (uint64_t)nRead, stored.data(), (uint64_t)windowsRead, 0, &first);
+    const int rc = ozcs_verify((int)type, (uint32_t)bpc, data.data(), (uint64_t)nRead, stored.data(), (uint64_t)windowsRead, 0, &first);
     if (rc != OZCS_OK) throw OzoneChecksumException(std::string(ozcs_last_error()));
-    if (first >= 0) {
+  }
+  // the reference's order of events, replayed: window i is throttled, then judged, and the first failing window
+  // ends the scan (:294-311) -- the throttler never sees a window behind the failure
+  for (long long i = 0; i < windowsRead; i++) {
+    if (throttler) throttler(std::min(bpc, nRead - i * bpc));
+    if (type == ChecksumType::NONE)  // computeChecksum yields no checksums for NONE: getChecksums().get(0) throws (:297-298)
+      throw std::out_of_range("Index: 0, Size: 0");
+    if (i == first) {
       const size_t woff = (size_t)(first * bpc), wlen = (size_t)std::min(bpc, nRead - first * bpc);
       const ChecksumData actual = Checksum(type, (int)bpc).computeChecksum(data.data() + woff, wlen);
       throw OzoneChecksumException("Inconsistent read for chunk=" + chunkInfoToString(chunkName, chunkOffset, chunkLen) +

@@ -9,6 +9,8 @@
 #pragma once
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
+#include <map>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -146,6 +148,37 @@ class ChecksumData {
   std::vector<ByteString> checksums_;
 };
 
+// Which elements of a buffer list ChunkBufferImplWithByteBufferList.iterate visits, in order, given the elements'
+// lengths (ChunkBufferImplWithByteBufferList.java:59-78, 192-201).  iterate().next() calls findCurrent() every
+// time, and findCurrent() adds the limits of the consumed buffers to limitPrecedingCurrent without resetting it:
+// position() runs ahead of the bytes really consumed and hasRemaining() turns false early -- of four equal
+// elements three are visited, of 256 only 24.
+inline std::vector<size_t> referenceListWindows(const std::vector<size_t>& lengths) {
+  const size_t n = lengths.size();
+  std::vector<size_t> visited;
+  if (n == 0) return visited;
+  long long limit = 0;
+  for (size_t l : lengths) limit += (long long)l;
+  std::vector<size_t> pos(n, 0);
+  long long preceding = 0;
+  size_t cur = 0;
+  auto findCurrent = [&]() {  // :59-78
+    bool found = false;
+    for (size_t i = 0; i < n && !found; i++) {
+      if (pos[i] < lengths[i]) { found = true; cur = i; }
+      else preceding += (long long)lengths[i];
+    }
+    if (!found) { cur = n - 1; preceding -= (long long)lengths[cur]; }
+  };
+  findCurrent();  // the constructor's call, :56
+  while (limit - (preceding + (long long)pos[cur]) > 0) {  // hasNext() = hasRemaining()
+    findCurrent();
+    visited.push_back(cur);
+    pos[cur] = lengths[cur];
+  }
+  return visited;
+}
+
 // Checksum.java:43-299.
 class Checksum {
  public:
@@ -172,8 +205,17 @@ class Checksum {
 
   // computeChecksum(List<ByteString>) / computeChecksum(ChunkBuffer over a list): one element per window; an
   // element longer than bytesPerChecksum contributes only its first bytesPerChecksum bytes
-  // (Checksum.java:148-153, 186-198).  Every element is checksummed.
-  ChecksumData computeChecksum(const std::vector<ByteString>& byteStrings) const {
+  // (Checksum.java:148-153, 186-198).  By default every element is checksummed: the documented intent
+  // (Checksum.java:279-281) and what a Checksum patched to call this library yields.  referenceListQuirk = true
+  // reproduces the unpatched reference bit for bit: only the elements referenceListWindows() names.
+  ChecksumData computeChecksum(const std::vector<ByteString>& all, bool referenceListQuirk = false) const {
+    std::vector<ByteString> subset;
+    if (referenceListQuirk) {
+      std::vector<size_t> lengths;
+      for (const ByteString& b : all) lengths.push_back(b.size());
+      for (size_t i : referenceListWindows(lengths)) subset.push_back(all[i]);
+    }
+    const std::vector<ByteString>& byteStrings = referenceListQuirk ? subset : all;
     if (checksumType_ == ChecksumType::NONE) return ChecksumData(checksumType_, bytesPerChecksum_);
     const int t = (int)checksumType_;
     if (t < OZCS_NONE || t > OZCS_MD5) throw OzoneChecksumException(checksumType_);
@@ -221,12 +263,12 @@ class Checksum {
 
   // verifyChecksum(List<ByteString>, ChecksumData, int, boolean): Checksum.java:265-290.
   static bool verifyChecksum(const std::vector<ByteString>& byteStrings, const ChecksumData& checksumData,
-                             int startIndex, bool isSingleByteString) {
+                             int startIndex, bool isSingleByteString, bool referenceListQuirk = false) {
     if (checksumData.getChecksumType() == ChecksumType::NONE) return true;  // :269-272
     if (isSingleByteString)
       return verifyChecksum(byteStrings.at(0).data(), byteStrings.at(0).size(), checksumData, startIndex);  // :274-277
     const ChecksumData computed =
-        Checksum(checksumData.getChecksumType(), checksumData.getBytesPerChecksum()).computeChecksum(byteStrings);
+        Checksum(checksumData.getChecksumType(), checksumData.getBytesPerChecksum()).computeChecksum(byteStrings, referenceListQuirk);
     return checksumData.verifyChecksumDataMatches(computed, startIndex);  // :282-289
   }
 
@@ -243,6 +285,72 @@ class Checksum {
   }
   ChecksumType checksumType_;
   int bytesPerChecksum_;
+};
+
+// The three checksum keys of the client configuration group "ozone.client" (OzoneClientConfig.java:103-125) with
+// the validation of :143-151: checksum.type defaults to CRC32, bytes.per.checksum to 1MB and is raised to 16 KiB
+// (OzoneConfigKeys.java:340) with a warning when set lower, verify.checksum defaults to true.
+class OzoneClientConfig {
+ public:
+  static constexpr int OZONE_CLIENT_BYTES_PER_CHECKSUM_MIN_SIZE = 16 * 1024;
+
+  explicit OzoneClientConfig(const std::map<std::string, std::string>& conf = {}) {
+    auto get = [&](const char* key, const char* dflt) {
+      const auto it = conf.find(std::string("ozone.client.") + key);
+      return it == conf.end() ? std::string(dflt) : it->second;
+    };
+    checksumType_ = get("checksum.type", "CRC32");
+    bytesPerChecksum_ = (int)parseSize(get("bytes.per.checksum", "1MB"));
+    checksumVerify_ = lower(get("verify.checksum", "true")) == "true";
+    if (bytesPerChecksum_ < OZONE_CLIENT_BYTES_PER_CHECKSUM_MIN_SIZE) {
+      char w[200];
+      std::snprintf(w, sizeof w, "The checksum size (%d) is not allowed to be less than the minimum size (%d), "
+                    "resetting to the minimum size.", bytesPerChecksum_, OZONE_CLIENT_BYTES_PER_CHECKSUM_MIN_SIZE);
+      warning_ = w;
+      std::fprintf(stderr, "WARN OzoneClientConfig: %s\n", w);
+      bytesPerChecksum_ = OZONE_CLIENT_BYTES_PER_CHECKSUM_MIN_SIZE;
+    }
+  }
+
+  // ChecksumType.valueOf(checksumType): an unknown name is an error (OzoneClientConfig.java:199-201)
+  ChecksumType getChecksumType() const {
+    for (ChecksumType t : {ChecksumType::NONE, ChecksumType::CRC32, ChecksumType::CRC32C, ChecksumType::SHA256, ChecksumType::MD5})
+      if (checksumType_ == name(t)) return t;
+    throw std::invalid_argument("No enum constant ChecksumType." + checksumType_);
+  }
+  void setChecksumType(ChecksumType t) { checksumType_ = name(t); }
+  int getBytesPerChecksum() const { return bytesPerChecksum_; }
+  void setBytesPerChecksum(int n) { bytesPerChecksum_ = n; }  // the setter does not clamp, only validation does
+  bool isChecksumVerify() const { return checksumVerify_; }
+  void setChecksumVerify(bool v) { checksumVerify_ = v; }
+  const std::string& validationWarning() const { return warning_; }
+  // what BlockOutputStream builds once per stream (BlockOutputStream.java:174-175)
+  Checksum newChecksum() const { return Checksum(getChecksumType(), bytesPerChecksum_); }
+
+ private:
+  static std::string lower(std::string s) {
+    for (char& c : s) c = (char)std::tolower((unsigned char)c);
+    return s;
+  }
+  // ConfigType.SIZE: a number with an optional B / KB / MB / GB unit (binary multiples)
+  static long long parseSize(const std::string& text) {
+    std::string t;
+    for (char c : text) if (c != ' ') t.push_back((char)std::toupper((unsigned char)c));
+    long long mul = 1;
+    auto ends = [&](const char* suf) {
+      const std::string s(suf);
+      return t.size() >= s.size() && t.compare(t.size() - s.size(), s.size(), s) == 0;
+    };
+    if (ends("KB")) { mul = 1ll << 10; t.resize(t.size() - 2); }
+    else if (ends("MB")) { mul = 1ll << 20; t.resize(t.size() - 2); }
+    else if (ends("GB")) { mul = 1ll << 30; t.resize(t.size() - 2); }
+    else if (ends("B")) { t.resize(t.size() - 1); }
+    return (long long)(std::strtod(t.c_str(), nullptr) * (double)mul);
+  }
+  std::string checksumType_;
+  int bytesPerChecksum_;
+  bool checksumVerify_;
+  std::string warning_;
 };
 
 }  // namespace ozone

@@ -1,6 +1,6 @@
 /*
  * Java side of the JNI binding for libozcs (include/ozone_checksum.h).  Source only: the build image has no
- * JDK.  Modelled on org.apache.hadoop.util.NativeCRC32Wrapper (static methods, caller-allocated sums,
+ * JDK (tests/test_jni_shim.py keeps the native method list in step with ozcs_jni.c).  Modelled on org.apache.hadoop.util.NativeCRC32Wrapper (static methods, caller-allocated sums,
  * isAvailable() probe) so that Checksum can use it the way the reference's benchmarks use the Hadoop
  * native CRC.  Type constants are ContainerProtos.ChecksumType numbers, not Hadoop's 1/2.
  */
@@ -47,9 +47,15 @@ public final class GpuChecksum {
   public static native long calculateChunkedSumsByteArray(int bytesPerSum, int checksumType,
       byte[] sums, int sumsOffset, byte[] data, int dataOffset, int dataLength);
 
-  /** Same for direct buffers (position..limit of data; digests at sums.position()). */
-  public static native long calculateChunkedSums(int bytesPerSum, int checksumType,
-      ByteBuffer sums, ByteBuffer data);
+  /** Same for direct buffers (position..limit of data; digests at sums.position()).  Neither buffer's
+   *  position moves, as with ChecksumByteBufferImpl.update on array-backed buffers. */
+  public static long calculateChunkedSums(int bytesPerSum, int checksumType, ByteBuffer sums, ByteBuffer data) {
+    return calculateChunkedSumsDirect(bytesPerSum, checksumType, sums, sums.position(), sums.limit(),
+        data, data.position(), data.limit());
+  }
+
+  private static native long calculateChunkedSumsDirect(int bytesPerSum, int checksumType,
+      ByteBuffer sums, int sumsPosition, int sumsLimit, ByteBuffer data, int dataPosition, int dataLimit);
 
   /**
    * ozcs_verify: returns -1 when every window matches, the first mismatching index (relative to the
@@ -67,6 +73,11 @@ public final class GpuChecksum {
   public static native int pipeSubmit(long pipe, int ticket, int checksumType, int bytesPerSum, long length,
       ByteBuffer sums);
   public static native long pipeWait(long pipe, int ticket);
+  /** Any completed ticket: ticketStatusOut[0] = ticket, [1] = its status; returns its digest count or a negative
+   *  code (OZCS_EBUSY = -7: none complete yet; OZCS_EEMPTY = -6: nothing outstanding). */
+  public static native long pipeNextCompleted(long pipe, boolean block, int[] ticketStatusOut);
+  /** The slot number (0 .. slots-1) behind a ticket, for per-slot state on the Java side. */
+  public static native int pipeTicketSlot(int ticket);
 
   private static native boolean nativeAvailable();
 }

@@ -1,61 +1,98 @@
 /*
  * JNI shim between org.apache.hadoop.ozone.common.GpuChecksum and the C ABI (include/ozone_checksum.h).
- * Source only: the build image has no JDK (no jni.h), so this file has never been compiled here.
+ * The build image has no JDK (no jni.h), so no loadable shim has been built here; the file is kept
+ * syntax- and signature-checked against a declaration stub (tests/jni_stub/jni.h, tests/test_jni_shim.py).
  * Build where a JDK exists:
  *   gcc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -I../../include \
- *       ozcs_jni.c -L../csrc -lozcs -o libozcs_jni.so
+ *       ozcs_jni.c -L../csrc -lozcs -lpthread -o libozcs_jni.so
  *
- * Heap arrays are reached with GetPrimitiveArrayCritical (no copy on HotSpot; the library then stages
- * the bytes to the device), direct buffers with GetDirectBufferAddress.  Nothing calls back into the JVM.
- * The critical section spans the whole synchronous call, as in Hadoop's NativeCrc32 (about 0.2 ms for a
- * 4 MiB chunk); callers with very large arrays should use the pinned pipe (direct buffers) instead.
+ * No critical regions.  The library calls block on the GPU, may allocate and may start helper threads, none of
+ * which is allowed between GetPrimitiveArrayCritical and its release (the collector is locked out for that
+ * time).  Heap arrays are therefore copied out with Get<Type>ArrayRegion: a chunk that fits a slot of the
+ * shim's pinned pipe goes straight from the Java heap into pinned memory (one copy, which the GPU path needs
+ * anyway), larger ones and the verify inputs into a malloc'd buffer.  Direct buffers are used in place; their
+ * position and limit come from the Java side as arguments, so nothing here calls back into the JVM.
  */
 #include <jni.h>
+#include <pthread.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "ozone_checksum.h"
 
 #define JFN(name) Java_org_apache_hadoop_ozone_common_GpuChecksum_##name
+
+/* The shim's own pipe for heap-array chunks: 8 pinned slots of 8 MiB (a chunk is 4 MiB by default,
+ * ScmConfigKeys.java:134) on device 0, created on first use. */
+#define SHIM_SLOTS 8
+#define SHIM_SLOT_BYTES (8u << 20)
+static pthread_once_t g_pipe_once = PTHREAD_ONCE_INIT;
+static ozcs_pipe* g_pipe = NULL;
+static void make_pipe(void) {
+  if (ozcs_pipe_create(0, SHIM_SLOTS, SHIM_SLOT_BYTES, &g_pipe) != OZCS_OK) g_pipe = NULL;
+}
 
 JNIEXPORT jboolean JNICALL JFN(nativeAvailable)(JNIEnv* env, jclass cls) {
   (void)env; (void)cls;
   return ozcs_available() ? JNI_TRUE : JNI_FALSE;
 }
 
+/* Digests of `len` bytes at `d` into the Java array `sums`; returns the count or a negative code. */
+static jlong sums_to_array(JNIEnv* env, int rc, uint64_t n, int type, const uint8_t* out, jbyteArray sums, jint sumsOff) {
+  if (rc != OZCS_OK) return (jlong)rc;
+  (*env)->SetByteArrayRegion(env, sums, sumsOff, (jsize)(n * ozcs_digest_size(type)), (const jbyte*)out);
+  return (*env)->ExceptionCheck(env) ? (jlong)OZCS_EINVAL : (jlong)n;
+}
+
 JNIEXPORT jlong JNICALL JFN(calculateChunkedSumsByteArray)(JNIEnv* env, jclass cls, jint bpc, jint type,
     jbyteArray sums, jint sumsOff, jbyteArray data, jint dataOff, jint dataLen) {
   (void)cls;
   if (bpc <= 0 || dataLen < 0 || dataOff < 0 || sumsOff < 0) return OZCS_EINVAL;
-  const jsize sumsLen = (*env)->GetArrayLength(env, sums);
-  if ((jlong)dataOff + dataLen > (*env)->GetArrayLength(env, data) || sumsOff > sumsLen) return OZCS_EINVAL;
-  uint8_t* d = (uint8_t*)(*env)->GetPrimitiveArrayCritical(env, data, NULL);
-  if (!d) return OZCS_ENOMEM;
-  uint8_t* s = (uint8_t*)(*env)->GetPrimitiveArrayCritical(env, sums, NULL);
-  uint64_t n = 0;
-  int rc = OZCS_ENOMEM;
-  if (s) {
-    rc = ozcs_compute(type, (uint32_t)bpc, d + dataOff, (uint64_t)dataLen, s + sumsOff,
-                      (uint64_t)(sumsLen - sumsOff), &n);
-    (*env)->ReleasePrimitiveArrayCritical(env, sums, s, 0);
+  const size_t ds = ozcs_digest_size(type);
+  const uint64_t n = type == OZCS_NONE ? 0 : ozcs_num_checksums((uint64_t)dataLen, (uint32_t)bpc);
+  if ((jlong)dataOff + dataLen > (*env)->GetArrayLength(env, data)) return OZCS_EINVAL;
+  if ((jlong)sumsOff + (jlong)(n * ds) > (*env)->GetArrayLength(env, sums)) return OZCS_EINVAL;
+  if (n == 0) return ds || type == OZCS_NONE ? 0 : OZCS_EINVAL;
+  uint8_t* out = (uint8_t*)malloc(n * ds);
+  if (!out) return OZCS_ENOMEM;
+  jlong result;
+  uint64_t got = 0;
+  void* slot = NULL;
+  int ticket = -1;
+  pthread_once(&g_pipe_once, make_pipe);
+  if (g_pipe && (uint64_t)dataLen <= SHIM_SLOT_BYTES && n * ds <= (SHIM_SLOT_BYTES / 512 + 1) * 32 &&
+      ozcs_pipe_acquire(g_pipe, &slot, &ticket) == OZCS_OK) {
+    /* Java heap -> pinned slot in one copy, then copy + kernel through the pipe */
+    (*env)->GetByteArrayRegion(env, data, dataOff, dataLen, (jbyte*)slot);
+    int rc = ozcs_pipe_submit_slot(g_pipe, ticket, type, (uint32_t)bpc, (uint64_t)dataLen, out, n * ds);
+    if (rc == OZCS_OK) rc = ozcs_pipe_wait(g_pipe, ticket, &got);
+    result = sums_to_array(env, rc, got, type, out, sums, sumsOff);
+  } else {
+    uint8_t* d = (uint8_t*)malloc((size_t)dataLen);
+    if (!d) {
+      free(out);
+      return OZCS_ENOMEM;
+    }
+    (*env)->GetByteArrayRegion(env, data, dataOff, dataLen, (jbyte*)d);
+    const int rc = ozcs_compute(type, (uint32_t)bpc, d, (uint64_t)dataLen, out, n * ds, &got);
+    result = sums_to_array(env, rc, got, type, out, sums, sumsOff);
+    free(d);
   }
-  (*env)->ReleasePrimitiveArrayCritical(env, data, d, JNI_ABORT);
-  return rc == OZCS_OK ? (jlong)n : (jlong)rc;
+  free(out);
+  return result;
 }
 
-JNIEXPORT jlong JNICALL JFN(calculateChunkedSums)(JNIEnv* env, jclass cls, jint bpc, jint type,
-    jobject sums, jobject data) {
+JNIEXPORT jlong JNICALL JFN(calculateChunkedSumsDirect)(JNIEnv* env, jclass cls, jint bpc, jint type,
+    jobject sums, jint sumsPos, jint sumsLimit, jobject data, jint dataPos, jint dataLimit) {
   (void)cls;
   uint8_t* d = (uint8_t*)(*env)->GetDirectBufferAddress(env, data);
   uint8_t* s = (uint8_t*)(*env)->GetDirectBufferAddress(env, sums);
-  if (!d || !s || bpc <= 0) return OZCS_EINVAL;
-  /* position/limit are read through the Buffer accessors */
-  jclass bufCls = (*env)->FindClass(env, "java/nio/Buffer");
-  jmethodID pos = (*env)->GetMethodID(env, bufCls, "position", "()I");
-  jmethodID lim = (*env)->GetMethodID(env, bufCls, "limit", "()I");
-  const jint dp = (*env)->CallIntMethod(env, data, pos), dl = (*env)->CallIntMethod(env, data, lim);
-  const jint sp = (*env)->CallIntMethod(env, sums, pos), sl = (*env)->CallIntMethod(env, sums, lim);
+  if (!d || !s || bpc <= 0 || dataPos < 0 || dataLimit < dataPos || sumsPos < 0 || sumsLimit < sumsPos) return OZCS_EINVAL;
+  if (dataLimit > (*env)->GetDirectBufferCapacity(env, data) || sumsLimit > (*env)->GetDirectBufferCapacity(env, sums))
+    return OZCS_EINVAL;
   uint64_t n = 0;
-  const int rc = ozcs_compute(type, (uint32_t)bpc, d + dp, (uint64_t)(dl - dp), s + sp, (uint64_t)(sl - sp), &n);
+  const int rc = ozcs_compute(type, (uint32_t)bpc, d + dataPos, (uint64_t)(dataLimit - dataPos), s + sumsPos,
+                              (uint64_t)(sumsLimit - sumsPos), &n);
   return rc == OZCS_OK ? (jlong)n : (jlong)rc;
 }
 
@@ -64,21 +101,19 @@ JNIEXPORT jlong JNICALL JFN(verifyChunkedSumsByteArray)(JNIEnv* env, jclass cls,
   (void)cls;
   if (bpc <= 0 || dataLen < 0 || dataOff < 0 || sumsOff < 0 || numSums < 0 || startIndex < 0) return -1 + OZCS_EINVAL;
   if ((jlong)dataOff + dataLen > (*env)->GetArrayLength(env, data)) return -1 + OZCS_EINVAL;
-  {
-    const jlong ds = (jlong)ozcs_digest_size(type);
-    if ((jlong)sumsOff + numSums * ds > (*env)->GetArrayLength(env, sums)) return -1 + OZCS_EINVAL;
-  }
-  uint8_t* d = (uint8_t*)(*env)->GetPrimitiveArrayCritical(env, data, NULL);
-  if (!d) return -1 + OZCS_ENOMEM;
-  uint8_t* s = (uint8_t*)(*env)->GetPrimitiveArrayCritical(env, sums, NULL);
+  const jlong sumBytes = numSums * (jlong)ozcs_digest_size(type);
+  if ((jlong)sumsOff + sumBytes > (*env)->GetArrayLength(env, sums)) return -1 + OZCS_EINVAL;
+  uint8_t* d = (uint8_t*)malloc((size_t)dataLen + 1);
+  uint8_t* s = (uint8_t*)malloc((size_t)sumBytes + 1);
   int64_t first = -1;
   int rc = OZCS_ENOMEM;
-  if (s) {
-    rc = ozcs_verify(type, (uint32_t)bpc, d + dataOff, (uint64_t)dataLen, s + sumsOff, (uint64_t)numSums,
-                     (uint64_t)startIndex, &first);
-    (*env)->ReleasePrimitiveArrayCritical(env, sums, s, JNI_ABORT);
+  if (d && s) {
+    (*env)->GetByteArrayRegion(env, data, dataOff, dataLen, (jbyte*)d);
+    (*env)->GetByteArrayRegion(env, sums, sumsOff, (jsize)sumBytes, (jbyte*)s);
+    rc = ozcs_verify(type, (uint32_t)bpc, d, (uint64_t)dataLen, s, (uint64_t)numSums, (uint64_t)startIndex, &first);
   }
-  (*env)->ReleasePrimitiveArrayCritical(env, data, d, JNI_ABORT);
+  free(d);
+  free(s);
   return rc == OZCS_OK ? (jlong)first : (jlong)(-1 + rc);
 }
 
@@ -117,4 +152,22 @@ JNIEXPORT jlong JNICALL JFN(pipeWait)(JNIEnv* env, jclass cls, jlong pipe, jint 
   uint64_t n = 0;
   const int rc = ozcs_pipe_wait((ozcs_pipe*)(intptr_t)pipe, ticket, &n);
   return rc == OZCS_OK ? (jlong)n : (jlong)rc;
+}
+
+/* ticketStatusOut[0] = the completed ticket, [1] = its own OZCS_* outcome.  Returns its digest count, or a
+ * negative code when no ticket was handed out (OZCS_EBUSY: none complete yet, OZCS_EEMPTY: none outstanding). */
+JNIEXPORT jlong JNICALL JFN(pipeNextCompleted)(JNIEnv* env, jclass cls, jlong pipe, jboolean block, jintArray ticketStatusOut) {
+  (void)cls;
+  int ticket = -1, status = OZCS_OK;
+  uint64_t n = 0;
+  const int rc = ozcs_pipe_next_completed((ozcs_pipe*)(intptr_t)pipe, block ? 1 : 0, &ticket, &status, &n);
+  if (rc != OZCS_OK) return (jlong)rc;
+  const jint out[2] = {ticket, status};
+  (*env)->SetIntArrayRegion(env, ticketStatusOut, 0, 2, out);
+  return (jlong)n;
+}
+
+JNIEXPORT jint JNICALL JFN(pipeTicketSlot)(JNIEnv* env, jclass cls, jint ticket) {
+  (void)env; (void)cls;
+  return ozcs_pipe_ticket_slot(ticket);
 }

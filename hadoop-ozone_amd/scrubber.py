@@ -7,7 +7,8 @@ Here the chunk's windows are read in one go and checked by ONE ozcs_verify call 
 ozcs_verify_device launch); the observable behaviour is kept:
 
   * FILE_PER_BLOCK positions the file at the chunk's offset and never reads past the chunk (:276-285);
-  * the throttler sees every window's byte count, in order, before that window is judged (:294);
+  * window i is throttled, then judged, and the first failing window ends the scan: the throttler sees exactly
+    the windows the reference would have read up to the failure, in order, with the canceler passed through (:294);
   * the first failing window raises "Inconsistent read for chunk=... checksum item %d expected checksum ...
     actual checksum ... for block ..." with Java's Arrays.toString byte formatting (:299-311);
   * a file that ends early at a window boundary raises the "expected length=%d actual length=%d" form (:314-320),
@@ -30,8 +31,49 @@ def chunk_info_str(chunk_name, offset, length):
     return "ChunkInfo{chunkName='%s, offset=%d, len=%d}" % (chunk_name, offset, length)
 
 
-class Canceled(Exception):
-    pass
+def _read_chunk(chunk_offset, chunk_len, checksum_data, chunk_file, layout):
+    """The bytes the reference's loop would read for this chunk, in one go: `count` windows of bpc, the last one
+    cut for FILE_PER_BLOCK so that the next chunk is not read (KeyValueContainerCheck.java:276-285)."""
+    count = len(checksum_data.getChecksums())
+    bpc = checksum_data.getBytesPerChecksum()
+    want = count * bpc
+    if layout == FILE_PER_BLOCK and count and chunk_len % bpc != 0:
+        want = (count - 1) * bpc + chunk_len % bpc
+    with open(chunk_file, "rb") as f:
+        if layout == FILE_PER_BLOCK:
+            f.seek(chunk_offset)
+        return f.read(want) if want else b""
+
+
+def _replay(block_id, chunk_name, chunk_offset, chunk_len, checksum_data, data, first, throttler, canceler):
+    """Replays the reference's per-window order of events (KeyValueContainerCheck.java:279-320) over a chunk whose
+    windows were checked in bulk (`first` = first failing window, or -1): window i is throttled, then judged, and
+    the first failing window ends the loop -- later windows are neither throttled nor looked at.  The throttler
+    is DataTransferThrottler.throttle(numBytes, canceler): it may return early when the canceler says so, the
+    reference's loop goes on regardless, and so does this one."""
+    sums = checksum_data.getChecksums()
+    bpc = checksum_data.getBytesPerChecksum()
+    t = checksum_data.getChecksumType()
+    n_read = len(data)
+    windows_read = (n_read + bpc - 1) // bpc if bpc else 0
+    for i in range(windows_read):
+        if throttler is not None:
+            throttler(min(bpc, n_read - i * bpc), canceler)   # :294
+        if t == ChecksumType.NONE:
+            # Checksum.computeChecksum yields no checksums for NONE, so getChecksums().get(0) (:297-298) throws in
+            # the reference for a NONE chunk that carries stored checksums (one without them has no windows)
+            raise IndexError("Index: 0, Size: 0")
+        if i == first:                                        # :297-311
+            ds = native.DIGEST_SIZE[int(t)]
+            actual = native.compute(int(t), bpc, data[i * bpc:(i + 1) * bpc])[:ds]
+            raise OzoneChecksumException(
+                "Inconsistent read for chunk=%s checksum item %d expected checksum %s actual checksum %s for block %s"
+                % (chunk_info_str(chunk_name, chunk_offset, chunk_len), i, _java_bytes(sums[i]), _java_bytes(actual),
+                   block_id))
+    if n_read != chunk_len:                                   # :314-320
+        raise OzoneChecksumException("Inconsistent read for chunk=%s expected length=%d actual length=%d for block %s"
+                                     % (chunk_name, chunk_len, n_read, block_id))
+    return n_read
 
 
 def verifyChecksum(block_id, chunk_name, chunk_offset, chunk_len, checksum_data, chunk_file, layout,
@@ -39,72 +81,39 @@ def verifyChecksum(block_id, chunk_name, chunk_offset, chunk_len, checksum_data,
     """Checks one chunk of a closed container against its stored ChecksumData.
 
     throttler: callable(num_bytes, canceler) or None (DataTransferThrottler.throttle);
-    canceler: object with is_cancelled() or None.  Returns the number of bytes read."""
+    canceler: passed through to the throttler, as in the reference.  Returns the number of bytes read."""
     sums = checksum_data.getChecksums()
-    count = len(sums)
     bpc = checksum_data.getBytesPerChecksum()
     t = checksum_data.getChecksumType()
-    # bytes the reference's loop would ask for: `count` windows of bpc, the last one cut for FILE_PER_BLOCK
-    want = count * bpc
-    if layout == FILE_PER_BLOCK and count and chunk_len % bpc != 0:
-        want = (count - 1) * bpc + chunk_len % bpc
-    with open(chunk_file, "rb") as f:
-        if layout == FILE_PER_BLOCK:
-            f.seek(chunk_offset)
-        data = f.read(want) if want else b""
-    n_read = len(data)
-    windows_read = (n_read + bpc - 1) // bpc if bpc else 0
-    if throttler is not None:
-        for i in range(windows_read):
-            throttler(min(bpc, n_read - i * bpc), canceler)
-    if t != ChecksumType.NONE and windows_read:
-        ds = native.DIGEST_SIZE[int(t)]
+    data = _read_chunk(chunk_offset, chunk_len, checksum_data, chunk_file, layout)
+    windows_read = (len(data) + bpc - 1) // bpc if bpc else 0
+    first = -1
+    if windows_read and t != ChecksumType.NONE:
         rc, first = native.verify(int(t), bpc, data, b"".join(sums[:windows_read]), 0)
         if rc != native.OK:
             raise OzoneChecksumException(native.lib().ozcs_last_error().decode())
-        if first >= 0:
-            actual = native.compute(int(t), bpc, data[first * bpc:(first + 1) * bpc])[:ds]
-            raise OzoneChecksumException(
-                "Inconsistent read for chunk=%s checksum item %d expected checksum %s actual checksum %s for block %s"
-                % (chunk_info_str(chunk_name, chunk_offset, chunk_len), first, _java_bytes(sums[first]),
-                   _java_bytes(actual), block_id))
-    elif t == ChecksumType.NONE and windows_read:
-        # Checksum.computeChecksum yields no checksums for NONE, so getChecksums().get(0) fails in the
-        # reference; a NONE chunk with a non-empty stored list cannot occur (the list is empty, count == 0)
-        pass
-    if n_read != chunk_len:
-        raise OzoneChecksumException("Inconsistent read for chunk=%s expected length=%d actual length=%d for block %s"
-                                     % (chunk_name, chunk_len, n_read, block_id))
-    return n_read
+    return _replay(block_id, chunk_name, chunk_offset, chunk_len, checksum_data, data, first, throttler, canceler)
 
 
 def verifyBlock(block_id, chunks, layout, throttler=None, canceler=None):
     """The `for chunk in block.getChunks()` loop of KeyValueContainerCheck.scanData (:235-257) with ONE
     ozcs_verify_batch call for all chunks instead of one checksum call per window.
 
-    chunks: list of (chunk_name, chunk_offset, chunk_len, checksum_data, chunk_file).  Chunks are read and
-    throttled in order; the first chunk (in order) that fails raises what verifyChecksum would raise for it.
-    Returns the number of bytes read."""
+    chunks: list of (chunk_name, chunk_offset, chunk_len, checksum_data, chunk_file).  All chunks are read and
+    hashed in bulk first; then the reference's order of events is replayed chunk by chunk, window by window
+    (throttle, judge, stop at the first failure): the throttler sees exactly the windows the reference would
+    have read up to the failure, and the first chunk (in order) that fails raises what verifyChecksum raises
+    for it.  Returns the number of bytes read."""
     import ctypes
     import numpy as np
     reads = []
     for name, off, ln, cd, path in chunks:
-        sums = cd.getChecksums()
+        data = _read_chunk(off, ln, cd, path, layout)
         bpc = cd.getBytesPerChecksum()
-        want = len(sums) * bpc
-        if layout == FILE_PER_BLOCK and sums and ln % bpc != 0:
-            want = (len(sums) - 1) * bpc + ln % bpc
-        with open(path, "rb") as f:
-            if layout == FILE_PER_BLOCK:
-                f.seek(off)
-            data = f.read(want) if want else b""
         nwin = (len(data) + bpc - 1) // bpc if bpc else 0
-        if throttler is not None:
-            for i in range(nwin):
-                throttler(min(bpc, len(data) - i * bpc), canceler)
-        reads.append((np.frombuffer(data, dtype=np.uint8), b"".join(sums[:nwin]), nwin))
+        reads.append((np.frombuffer(data, dtype=np.uint8), b"".join(cd.getChecksums()[:nwin]), nwin))
     n = len(chunks)
-    arr = (native.OzcsVChunk * n)()
+    arr = (native.OzcsVChunk * max(1, n))()
     for i, ((name, off, ln, cd, path), (data, stored, nwin)) in enumerate(zip(chunks, reads)):
         t = cd.getChecksumType()
         arr[i].type = int(t) if nwin else int(ChecksumType.NONE)   # nothing read: only the length check applies
@@ -114,23 +123,12 @@ def verifyBlock(block_id, chunks, layout, throttler=None, canceler=None):
         arr[i].expected = ctypes.cast(ctypes.c_char_p(stored), ctypes.c_void_p).value
         arr[i].n_expected = nwin
         arr[i].start_index = 0
-    rc = native.lib().ozcs_verify_batch(arr, n)
+    rc = native.lib().ozcs_verify_batch(arr, n) if n else native.OK
     total = 0
     for i, ((name, off, ln, cd, path), (data, stored, nwin)) in enumerate(zip(chunks, reads)):
         if arr[i].status != native.OK:
             if rc in (native.ENODEV, native.EHIP, native.ENOMEM):
                 native.check(arr[i].status)
             raise OzoneChecksumException("verify failed for chunk %s: status %d" % (name, arr[i].status))
-        first = arr[i].first_mismatch
-        if first >= 0:
-            t, bpc = cd.getChecksumType(), cd.getBytesPerChecksum()
-            ds = native.DIGEST_SIZE[int(t)]
-            actual = native.compute(int(t), bpc, data[first * bpc:(first + 1) * bpc])[:ds]
-            raise OzoneChecksumException(
-                "Inconsistent read for chunk=%s checksum item %d expected checksum %s actual checksum %s for block %s"
-                % (chunk_info_str(name, off, ln), first, _java_bytes(cd.getChecksums()[first]), _java_bytes(actual), block_id))
-        if data.size != ln:
-            raise OzoneChecksumException("Inconsistent read for chunk=%s expected length=%d actual length=%d for block %s"
-                                         % (name, ln, data.size, block_id))
-        total += data.size
+        total += _replay(block_id, name, off, ln, cd, data, arr[i].first_mismatch, throttler, canceler)
     return total

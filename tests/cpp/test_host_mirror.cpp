@@ -121,6 +121,53 @@ int main() {
     } catch (const OzoneChecksumException& e) { EXPECT(e.index() == 1); }
   }
 
+  // ---- client configuration keys (OzoneClientConfig.java:103-125, 143-151) ----
+  {
+    const OzoneClientConfig dflt;
+    EXPECT(dflt.getChecksumType() == ChecksumType::CRC32);
+    EXPECT(dflt.getBytesPerChecksum() == 1024 * 1024);
+    EXPECT(dflt.isChecksumVerify());
+    typedef std::map<std::string, std::string> Conf;
+    OzoneClientConfig low(Conf{{"ozone.client.bytes.per.checksum", "4KB"}, {"ozone.client.checksum.type", "MD5"},
+                               {"ozone.client.verify.checksum", "false"}});
+    EXPECT(low.getBytesPerChecksum() == 16 * 1024);   // raised to the minimum, with the reference's warning
+    EXPECT(low.validationWarning() == "The checksum size (4096) is not allowed to be less than the minimum size (16384), "
+                                      "resetting to the minimum size.");
+    EXPECT(low.getChecksumType() == ChecksumType::MD5 && !low.isChecksumVerify());
+    EXPECT(OzoneClientConfig(Conf{{"ozone.client.bytes.per.checksum", "256KB"}}).getBytesPerChecksum() == 262144);
+    low.setBytesPerChecksum(10);                       // the setter does not clamp
+    EXPECT(low.getBytesPerChecksum() == 10);
+    try {
+      OzoneClientConfig(Conf{{"ozone.client.checksum.type", "CRC64"}}).getChecksumType();
+      EXPECT(!"unknown type name accepted");
+    } catch (const std::invalid_argument&) {}
+  }
+
+  // ---- list inputs: every element by default, the reference's subset on request ----
+  {
+    EXPECT((referenceListWindows({4, 4, 4, 4}) == std::vector<size_t>{0, 1, 2}));
+    EXPECT((referenceListWindows({20, 20, 20, 20, 20}) == std::vector<size_t>{0, 1, 2, 3}));
+    EXPECT(referenceListWindows(std::vector<size_t>(256, 16384)).size() == 24);
+    EXPECT((referenceListWindows({0, 5, 0, 5, 5, 5}) == std::vector<size_t>{1, 3, 4}));
+    EXPECT(referenceListWindows({}).empty());
+    std::string bytes(100, '\0');
+    oracle_fill_splitmix64(77, (uint8_t*)&bytes[0], bytes.size());
+    std::vector<ByteString> parts;
+    for (int o = 0; o < 100; o += 20) parts.push_back(bytes.substr(o, 20));
+    const std::vector<ByteString> full = oracle_sums(ChecksumType::CRC32, 20, bytes);
+    const Checksum ck(ChecksumType::CRC32, 20);
+    EXPECT(ck.computeChecksum(parts).getChecksums() == full);
+    EXPECT(ck.computeChecksum(parts, true).getChecksums() == std::vector<ByteString>(full.begin(), full.begin() + 4));
+    std::vector<ByteString> bad = parts;
+    bad[4][0] ^= 1;
+    const ChecksumData stored(ChecksumType::CRC32, 20, full);
+    try {
+      Checksum::verifyChecksum(bad, stored, 0, false);
+      EXPECT(!"corrupt fifth window accepted");
+    } catch (const OzoneChecksumException& e) { EXPECT(e.index() == 4); }
+    EXPECT(Checksum::verifyChecksum(bad, stored, 0, false, true));   // the unpatched reference never looks at it
+  }
+
   // ---- scrubber: TestKeyValueContainerCheck shape (SHA-256, ragged last window), both layouts ----
   {
     const int bpc = 2048;
@@ -149,6 +196,14 @@ int main() {
       const std::string w = e.what();
       EXPECT(w.find("Inconsistent read for chunk=ChunkInfo{chunkName='c1, offset=5000, len=7168} checksum item 1 expected checksum [") == 0);
       EXPECT(w.find(" for block blk#1") == w.size() - 16);
+    }
+    seen.clear();   // window i is throttled, then judged; the failure in window 1 ends the scan
+    try {
+      verifyChunkFile("blk#1", "c1", chunkOffset, chunkLen, stored, path, ChunkLayOutVersion::FILE_PER_BLOCK,
+                      [&](long long n) { seen.push_back(n); });
+      EXPECT(!"corrupt chunk accepted");
+    } catch (const OzoneChecksumException&) {
+      EXPECT((seen == std::vector<long long>{2048, 2048}));
     }
     put(file.substr(0, (size_t)chunkOffset + 4096));   // truncated at a window boundary
     try {

@@ -69,3 +69,53 @@ def test_unrecognized_type_and_empty_input():
     assert Checksum(ChecksumType.CRC32, 10).computeChecksum(b"").getChecksums() == []
     assert Checksum.int2ByteString(0xCBF43926) == bytes.fromhex("cbf43926")
     assert Checksum.int2ByteString(-1) == b"\xff\xff\xff\xff"
+
+
+# ---- OzoneClientConfig checksum keys (OzoneClientConfig.java:103-125, 143-151)
+
+def test_client_config_defaults_and_clamp(caplog):
+    from hadoop_ozone_amd.checksum import OZONE_CLIENT_BYTES_PER_CHECKSUM_MIN_SIZE, ChecksumType, OzoneClientConfig
+    c = OzoneClientConfig()
+    assert c.getChecksumType() == ChecksumType.CRC32
+    assert c.getBytesPerChecksum() == 1024 * 1024
+    assert c.isChecksumVerify() is True
+    assert OZONE_CLIENT_BYTES_PER_CHECKSUM_MIN_SIZE == 16 * 1024
+    # below the minimum: raised to 16 KiB, with the reference's warning
+    with caplog.at_level("WARNING"):
+        c = OzoneClientConfig({"ozone.client.bytes.per.checksum": "4KB", "ozone.client.checksum.type": "SHA256",
+                               "ozone.client.verify.checksum": "false"})
+    assert c.getBytesPerChecksum() == 16 * 1024
+    assert "The checksum size (4096) is not allowed to be less than the minimum size (16384), resetting to the minimum size." in caplog.text
+    assert c.getChecksumType() == ChecksumType.SHA256 and c.isChecksumVerify() is False
+    # at and above the minimum: kept; sizes accept the SIZE units
+    for text, want in (("16KB", 16384), ("16384", 16384), ("256KB", 262144), ("2MB", 2 << 20), (12345678, 12345678)):
+        assert OzoneClientConfig({"ozone.client.bytes.per.checksum": text}).getBytesPerChecksum() == want
+    # the setter does not clamp (only validate() does), an unknown type name fails on use
+    c.setBytesPerChecksum(10)
+    assert c.getBytesPerChecksum() == 10
+    c.setChecksumType(ChecksumType.MD5)
+    ck = c.newChecksum()
+    assert (ck.checksumType, ck.bytesPerChecksum) == (ChecksumType.MD5, 10)
+    with pytest.raises(ValueError):
+        OzoneClientConfig({"ozone.client.checksum.type": "CRC64"}).getChecksumType()
+
+
+# ---- which list elements the reference's ChunkBufferImplWithByteBufferList.iterate visits
+
+def test_reference_list_iteration_trace():
+    from hadoop_ozone_amd.checksum import reference_list_windows
+    # four 4-byte elements: after the third next() limitPrecedingCurrent is 12, position() 16 = limit, and the
+    # fourth element is never visited (ChunkBufferImplWithByteBufferList.java:59-78, 192-201)
+    assert reference_list_windows([4, 4, 4, 4]) == [0, 1, 2]
+    assert reference_list_windows([]) == []
+    assert reference_list_windows([7]) == [0]
+    assert reference_list_windows([7, 7]) == [0, 1]
+    assert reference_list_windows([7, 7, 7]) == [0, 1, 2]
+    assert reference_list_windows([20] * 5) == [0, 1, 2, 3]       # TestChunkInputStream's 100 bytes at 20
+    assert reference_list_windows([16384] * 256) == list(range(24))  # a 4 MiB chunk read back at 16 KiB windows
+    assert reference_list_windows([1 << 20] * 4) == [0, 1, 2]      # ... and at the default 1 MiB
+    assert reference_list_windows([0, 5, 0, 5, 5, 5]) == [1, 3, 4]  # empty elements are stepped over
+    # after the k-th next() position() is (k(k-1)/2 + 1) elements, so k is the first count with k(k-1)/2 + 1 >= n
+    for n in range(1, 80):
+        k = len(reference_list_windows([3] * n))
+        assert k * (k - 1) // 2 + 1 >= n and (k == 1 or (k - 1) * (k - 2) // 2 + 1 < n)
