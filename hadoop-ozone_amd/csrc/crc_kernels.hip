@@ -683,7 +683,9 @@ hipError_t launch_flat(const CrcLaunch& p, int lpw, int unr, int blocks, hipStre
     case 8 * 8 + 1: crc_flat_kernel<8, MODE, 1><<<blocks, kThreads, 0, stream>>>(p); break;
     case 8 * 8 + 2: crc_flat_kernel<8, MODE, 2><<<blocks, kThreads, 0, stream>>>(p); break;
     case 16 * 8 + 1: crc_flat_kernel<16, MODE, 1><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 16 * 8 + 2: crc_flat_kernel<16, MODE, 2><<<blocks, kThreads, 0, stream>>>(p); break;
     case 32 * 8 + 1: crc_flat_kernel<32, MODE, 1><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 32 * 8 + 2: crc_flat_kernel<32, MODE, 2><<<blocks, kThreads, 0, stream>>>(p); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -756,6 +758,11 @@ int crc_choose_lpw(uint64_t n_windows, uint32_t bpc, int num_cus) {
   // measured twice over: 16 lanes beat 8 at 4 KiB (6.53 against 6.41 TB/s) and 8 KiB windows (6.67 against
   // 6.33), and nowhere else
   if (want == 8 && bpc >= 4096 && bpc < 16384) want = 16;
+  // between 16 and 64 KiB (exclusive) 8 lanes lose to 32: 6.53-6.58 against 6.74-6.76 TB/s at 32 KiB, 6.58 against
+  // 6.80 at 24 KiB, 6.54 against 6.82 at 40 KiB, 6.66 against 6.79 at 56 KiB (16 lanes: 5.8 at 32 KiB); at
+  // 16 KiB and from 64 KiB on 8 lanes are best again (6.76 / 7.02).  The ranking follows no simple rule of the
+  // stride between the pieces one instruction reads, so it is taken from the measurements.
+  if (want == 8 && bpc > 16384 && bpc < 65536) want = 32;
   const int cap = bpc >= 4096 ? 64 : bpc >= 2048 ? 32 : bpc >= 1024 ? 16 : bpc >= 256 ? 8 : 4;
   const int lpw = want < cap ? want : cap;
   return lpw == 64 ? 0 : lpw;
@@ -797,6 +804,7 @@ hipError_t crc_launch(const CrcLaunch& launch, int mode, int group, int num_cus,
                          (mode != kModeCompute || (reinterpret_cast<uintptr_t>(p.sums) & 3u) == 0);
     if (gapless) {
       int fl = lpw, fu = (p.bpc <= 256 && p.bpc % (32u * lpw) == 0) ? 2 : 1;
+      if (fl == 16 && p.bpc == 8192) fu = 2;  // measured: 6.82 against 6.73 TB/s with one stripe per load group
       if (g_force_flat > 0) {
         fl = g_force_flat / 8;
         fu = g_force_flat % 8;

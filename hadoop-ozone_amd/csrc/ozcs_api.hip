@@ -253,10 +253,15 @@ static int check_type_bpc(int type, uint32_t bpc) {
   return OZCS_OK;
 }
 
+// Device for a single host-pointer call.  A caller thread keeps the device it was first given (threads are dealt
+// out round-robin): the callers are long-lived writer / reader / scanner threads, and staying put lets each reuse
+// the pooled staging buffers of its device instead of growing a set on every device in turn.
 static int pick_device() {
   Global& g = global();
   const size_t n = g.devs.size();
-  return g.devs[g.rr.fetch_add(1, std::memory_order_relaxed) % n].id;
+  thread_local size_t mine = (size_t)-1;
+  if (mine == (size_t)-1) mine = (size_t)g.rr.fetch_add(1, std::memory_order_relaxed);
+  return g.devs[mine % n].id;
 }
 
 // Host-pointer compute of one chunk on one device, synchronous.

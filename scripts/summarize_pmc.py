@@ -1,9 +1,14 @@
 #!/usr/bin/env python3
-"""Builds profiles/pmc_summary.json and the kernel-stats CSV from the rocprofv3 output that
-scripts/profile_r01.sh leaves under gpurun_out/ (prof_trace/, prof_pmc_*/), for the headline workload.
+"""Turns the rocprofv3 output of scripts/profile_r02.sh (gpurun_out/prof_<TAG>_*) into an entry of
+profiles/pmc_summary.json and a kernel-stats CSV under profiles/.
 
-HBM bytes per launch = FETCH_SIZE [KiB] x 1024 x 2 + WRITE_SIZE [KiB] x 1024: gfx950 tallies a 128-byte read
-request as 64 bytes in FETCH_SIZE (cross-check: TCC_EA0_RDREQ_sum x 128 B)."""
+    scripts/summarize_pmc.py TAG KEY KERNEL_SUBSTRING ALGORITHMIC_BYTES [WARMUP_LAUNCHES [WAVE_BLOCKS]]
+
+KEY is "<type>-<bpc>-<blocks>" as bench.py looks it up.  HBM bytes per launch = FETCH_SIZE [KiB] x 1024 x 2 +
+WRITE_SIZE [KiB] x 1024: gfx950 tallies a 128-byte read request as 64 bytes in FETCH_SIZE (cross-check:
+TCC_EA0_RDREQ_sum x 128 B).  The entry is stamped with the hash of the kernel sources it was taken from; bench.py
+ignores entries whose stamp differs from the sources of the library it runs.  WAVE_BLOCKS (digests): wavefronts x
+64-byte blocks per window of one launch; SQ_INSTS_VALU divided by it is the vector instructions per block."""
 import collections
 import csv
 import glob
@@ -13,16 +18,17 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, "gpurun_out")
-KEY = sys.argv[1] if len(sys.argv) > 1 else "CRC32-1048576-64"
-KERNEL = sys.argv[2] if len(sys.argv) > 2 else "crc_windows_kernel"
-ALG_BYTES = int(sys.argv[3]) if len(sys.argv) > 3 else 64 * 256 * (1 << 20) + 64 * 256 * 4
+TAG, KEY, KERNEL, ALG_BYTES = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
+WARMUP = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+WAVE_BLOCKS = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 
 
 def counters():
     agg = collections.defaultdict(list)
     kernel = None
-    for f in glob.glob(os.path.join(OUT, "prof_pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    for f in sorted(glob.glob(os.path.join(OUT, "prof_%s_pmc_*" % TAG, "**", "*counter_collection.csv"), recursive=True)):
         for r in csv.DictReader(open(f)):
             if KERNEL in r["Kernel_Name"]:
                 kernel = r["Kernel_Name"]
@@ -30,29 +36,49 @@ def counters():
     return kernel, {k: {"launches": len(v), "avg": sum(v) / len(v), "min": min(v), "max": max(v)} for k, v in sorted(agg.items())}
 
 
-def kernel_stats():
-    for f in glob.glob(os.path.join(OUT, "prof_trace", "**", "*kernel_stats.csv"), recursive=True):
-        shutil.copy(f, os.path.join(ROOT, "profiles", "r01_kernel_stats_crc32_1MiB_64blocks.csv"))
+def kernel_times():
+    """(average over all profiled launches as rocprofv3 --stats reports it, calls, average without the first WARMUP
+    launches from the kernel trace)."""
+    avg_ns, calls, warm = None, 0, None
+    for f in glob.glob(os.path.join(OUT, "prof_%s_trace" % TAG, "**", "*kernel_stats.csv"), recursive=True):
+        shutil.copy(f, os.path.join(ROOT, "profiles", "r02_kernel_stats_%s.csv" % TAG))
         for r in csv.DictReader(open(f)):
             if KERNEL in r["Name"]:
-                return float(r["AverageNs"]), int(r["Calls"])
-    return None, 0
+                avg_ns, calls = float(r["AverageNs"]), int(r["Calls"])
+    for f in glob.glob(os.path.join(OUT, "prof_%s_trace" % TAG, "**", "*kernel_trace.csv"), recursive=True):
+        rows = [r for r in csv.DictReader(open(f)) if KERNEL in r["Kernel_Name"]]
+        rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+        d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows][WARMUP:]
+        if d:
+            warm = sum(d) / len(d)
+    return avg_ns, calls, warm
 
 
 def main():
+    from hadoop_ozone_amd import native
     kernel, c = counters()
-    avg_ns, calls = kernel_stats()
-    fetch = c["FETCH_SIZE"]["avg"] * 1024 * 2
-    write = c["WRITE_SIZE"]["avg"] * 1024
+    avg_ns, calls, warm_ns = kernel_times()
     rec = {
-        "command": "rocprofv3 --kernel-trace --stats / --pmc <one block per run> -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline",
+        "command": "scripts/profile_r02.sh (rocprofv3 --kernel-trace --stats; --pmc, one block per run) -- python3 bench.py "
+                   "--no-cpu-baseline ...",
+        "source_hash": native.source_hash(),
         "kernel": kernel, "kernel_avg_ns_profiled": avg_ns, "kernel_calls_profiled": calls,
-        "algorithmic_bytes_per_launch": ALG_BYTES, "hbm_bytes_per_launch": round(fetch + write),
-        "fetch_bytes": round(fetch), "write_bytes": round(write),
-        "correction": "FETCH_SIZE [KiB] x 1024 x 2 (gfx950 tallies 128-B read requests at 64 B; cross-check: "
-                      "TCC_EA0_RDREQ_sum x 128 B = %d); WRITE_SIZE [KiB] x 1024" % round(c.get("TCC_EA0_RDREQ_sum", {"avg": 0})["avg"] * 128),
-        "counters": c,
+        "kernel_avg_ns_after_warmup": warm_ns, "warmup_launches_excluded": WARMUP,
+        "algorithmic_bytes_per_launch": ALG_BYTES, "counters": c,
     }
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        fetch = c["FETCH_SIZE"]["avg"] * 1024 * 2
+        write = c["WRITE_SIZE"]["avg"] * 1024
+        rec.update({
+            "hbm_bytes_per_launch": round(fetch + write), "fetch_bytes": round(fetch), "write_bytes": round(write),
+            "correction": "FETCH_SIZE [KiB] x 1024 x 2 (gfx950 tallies 128-B read requests at 64 B; cross-check: "
+                          "TCC_EA0_RDREQ_sum x 128 B = %d); WRITE_SIZE [KiB] x 1024"
+                          % round(c.get("TCC_EA0_RDREQ_sum", {"avg": 0})["avg"] * 128)})
+    if WAVE_BLOCKS and "SQ_INSTS_VALU" in c:
+        rec["valu_per_block_lane"] = round(c["SQ_INSTS_VALU"]["avg"] / WAVE_BLOCKS, 1)
+        rec["wave_blocks_per_launch"] = WAVE_BLOCKS
+    if "SQ_LDS_BANK_CONFLICT" in c and "SQ_LDS_IDX_ACTIVE" in c and c["SQ_LDS_IDX_ACTIVE"]["avg"]:
+        rec["lds_bank_conflict_frac"] = round(c["SQ_LDS_BANK_CONFLICT"]["avg"] / c["SQ_LDS_IDX_ACTIVE"]["avg"], 5)
     path = os.path.join(ROOT, "profiles", "pmc_summary.json")
     try:
         allrec = json.load(open(path))
@@ -60,7 +86,9 @@ def main():
         allrec = {}
     allrec[KEY] = rec
     json.dump(allrec, open(path, "w"), indent=1)
-    print(json.dumps({k: rec[k] for k in ("kernel", "kernel_avg_ns_profiled", "algorithmic_bytes_per_launch", "hbm_bytes_per_launch")}))
+    print(json.dumps({k: rec.get(k) for k in ("kernel", "kernel_avg_ns_profiled", "kernel_avg_ns_after_warmup",
+                                               "algorithmic_bytes_per_launch", "hbm_bytes_per_launch", "valu_per_block_lane",
+                                               "lds_bank_conflict_frac", "source_hash")}))
 
 
 if __name__ == "__main__":
