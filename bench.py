@@ -116,6 +116,32 @@ def cpu_baseline(sample, bpc):
     }
 
 
+def cpu_baseline_other(type_name, type_id, sample, bpc):
+    """CPU baseline for the configurations other than the headline one: the same algorithm on the host cores over
+    a bounded sample.  CRC32C: PCLMULQDQ folding (the scheme of the JDK's CRC32C intrinsic) plus the slice-by-8
+    restatement; SHA-256 / MD5: the plain C restatements of FIPS 180-4 / RFC 1321 (the JDK's MessageDigest uses
+    SHA-NI / hand-tuned intrinsics where the CPU has them, so the JVM may be faster than this port)."""
+    import oracle
+    cores = min(16, os.cpu_count() or 1)
+    if type_name == "CRC32C":
+        tn = oracle.bench_clmul(type_id, bpc, sample, threads=cores, reps=6)
+        t1 = oracle.bench_clmul(type_id, bpc, sample[: min(sample.nbytes, 1 << 30)], threads=1, reps=2)
+        ts = oracle.bench(type_id, bpc, sample, threads=cores, reps=4)
+        extra = {"one_core_GBps": round(min(sample.nbytes, 1 << 30) / t1 / 1e9, 3),
+                 "slice_by_8_GBps": round(sample.nbytes / ts / 1e9, 3)}
+        engine = "PCLMULQDQ folding as in the JDK intrinsic" if oracle.has_clmul() else "table method"
+    else:
+        tn = oracle.bench(type_id, bpc, sample, threads=cores, reps=2)
+        t1 = oracle.bench(type_id, bpc, sample[: min(sample.nbytes, 256 * MIB)], threads=1, reps=1)
+        extra = {"one_core_GBps": round(min(sample.nbytes, 256 * MIB) / t1 / 1e9, 3)}
+        engine = "plain C from the specification, no SHA-NI"
+    out = {"value": round(sample.nbytes / tn / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": "port",
+           "sample": "%d MiB of the same random bytes, %s at %d B windows, best pass on %d threads; C restatement (%s), "
+                     "not the JVM" % (sample.nbytes // MIB, type_name, bpc, cores, engine)}
+    out.update(extra)
+    return out
+
+
 def jvm_baseline(bpc, cores):
     """The reference's production engines (java.util.zip.CRC32 / CRC32C) timed by bench/java/CrcBaseline.java, when
     this box has a JDK; None otherwise (the build image and the project's GPU boxes have none).  Bounded: about
@@ -291,12 +317,15 @@ def main():
             }
             if prof_note:
                 out["roofline"]["traffic_note"] = prof_note
-        if world == 1 and not args.no_cpu_baseline and args.type == "CRC32" and args.mode == "compute":
+        if world == 1 and not args.no_cpu_baseline and args.type == "CRC32":
             sample = data[: min(nbytes, 2 << 30)].cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(sample, args.bpc)
             jvm = jvm_baseline(args.bpc, out["cpu_baseline"]["cores"])
             if jvm:   # the real thing beside the C restatement, when a JDK happens to exist
                 out["cpu_baseline"]["jvm"] = jvm
+        elif world == 1 and not args.no_cpu_baseline:
+            sample = data[: min(nbytes, (2 << 30) if args.type == "CRC32C" else (1 << 30))].cpu().numpy()
+            out["cpu_baseline"] = cpu_baseline_other(args.type, type_id, sample, args.bpc)
         elif world == 1:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -8,11 +8,13 @@
  *   chunk      what Checksum.computeChecksum does per chunk on the write path (Checksum.java:155-198): a 4 MiB
  *              chunk, a fresh engine per call, one 4-byte big-endian digest per window
  *
- * on one thread and on T threads over independent chunks (many open BlockOutputStreams).  Prints one JSON line.
+ * on one thread and on T threads over independent chunks (many open BlockOutputStreams), plus
+ * MessageDigest SHA-256 / MD5 per window (Checksum.java:46-60) on T threads.  Prints one JSON line.
  *
  *   javac -d /tmp/ozcs_java bench/java/CrcBaseline.java && java -cp /tmp/ozcs_java CrcBaseline [bpc] [threads] [seconds]
  */
 import java.nio.ByteBuffer;
+import java.security.MessageDigest;
 import java.util.Random;
 import java.util.concurrent.atomic.AtomicLong;
 import java.util.function.Supplier;
@@ -99,6 +101,44 @@ public final class CrcBaseline {
     return total.get() / ((System.nanoTime() - t0) / 1e9) / 1e9;
   }
 
+  /** GB/s of MessageDigest per window (Checksum.java:46-60: reset, update, digest) on `threads` threads. */
+  private static double digests(String algorithm, byte[] data, int bpc, int threads, double seconds)
+      throws InterruptedException {
+    final AtomicLong total = new AtomicLong();
+    final long t0 = System.nanoTime();
+    final long end = t0 + (long) (seconds * 1e9);
+    final Thread[] ts = new Thread[threads];
+    final int perBuffer = data.length / CHUNK;
+    for (int t = 0; t < threads; t++) {
+      final int first = t;
+      ts[t] = new Thread(() -> {
+        try {
+          final MessageDigest md = MessageDigest.getInstance(algorithm);
+          long bytes = 0;
+          int chunk = first % perBuffer;
+          do {
+            final int base = chunk * CHUNK;
+            for (int off = 0; off < CHUNK; off += bpc) {
+              md.reset();
+              md.update(data, base + off, Math.min(bpc, CHUNK - off));
+              md.digest();
+            }
+            bytes += CHUNK;
+            chunk = (chunk + threads) % perBuffer;
+          } while (System.nanoTime() < end);
+          total.addAndGet(bytes);
+        } catch (java.security.NoSuchAlgorithmException e) {
+          throw new IllegalStateException(e);
+        }
+      });
+      ts[t].start();
+    }
+    for (Thread t : ts) {
+      t.join();
+    }
+    return total.get() / ((System.nanoTime() - t0) / 1e9) / 1e9;
+  }
+
   public static void main(String[] args) throws Exception {
     final int bpc = args.length > 0 ? Integer.parseInt(args[0]) : 1 << 20;
     final int threads = args.length > 1 ? Integer.parseInt(args[1]) : Runtime.getRuntime().availableProcessors();
@@ -119,6 +159,9 @@ public final class CrcBaseline {
       sb.append(String.format(", \"crc32c_streaming_one_thread_GBps\": %.3f", streaming(c32c, data, bpc, seconds)));
       sb.append(String.format(", \"crc32c_chunk_all_threads_GBps\": %.3f", chunks(c32c, data, bpc, threads, seconds)));
     }
+    digests("MD5", data, bpc, 1, 0.5);
+    sb.append(String.format(", \"sha256_all_threads_GBps\": %.3f", digests("SHA-256", data, bpc, threads, seconds)));
+    sb.append(String.format(", \"md5_all_threads_GBps\": %.3f", digests("MD5", data, bpc, threads, seconds)));
     System.out.println(sb.append("}"));
   }
 }

@@ -53,7 +53,12 @@ constexpr int kNibOps = 14;                                    // operators 0..1
 constexpr uint32_t kNibOpBytes = 8u * 16u * 4u;                // 512 B per operator
 constexpr uint32_t kNibOff = kMainBytes;
 constexpr uint32_t kPartOff = kNibOff + kNibOps * kNibOpBytes;  // 2 x 16 partial registers
-constexpr uint32_t kLdsBytes = kPartOff + 2u * kWaves * 4u;
+// byte tables of the "advance 4 bytes" operator in 4 copies (entry b of table j, copy r at
+// kZ4Off + j*4096 + b*16 + r*4): the small-window kernels merge the four accumulators of a unit with it
+constexpr uint32_t kZ4Off = (kPartOff + 2u * kWaves * 4u + 15u) & ~15u;
+constexpr uint32_t kZ4Bytes = 4u * 256u * 4u * 4u;
+constexpr uint32_t kLdsBytes = kZ4Off + kZ4Bytes;
+static_assert(kLdsBytes <= 160u * 1024u, "one workgroup's tables must fit the CU's 160 KiB of LDS");
 
 __device__ __forceinline__ uint32_t lds_u32(const char* base, uint32_t off) {
   return *reinterpret_cast<const uint32_t*>(base + off);
@@ -213,6 +218,12 @@ __device__ __forceinline__ void build_tables(char* lds, const PolyBasis& pb, int
   const uint4 v4 = make_uint4(v, v, v, v);
 #pragma unroll
   for (int r = 0; r < 8; r++) dst[r] = v4;
+  {
+    uint32_t z = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) z ^= ((b >> i) & 1) ? pb.op[kOpZ4].v[8 * j + i] : 0u;
+    *reinterpret_cast<uint4*>(lds + kZ4Off + (j * 256 + b) * 16) = make_uint4(z, z, z, z);
+  }
   for (int e = tid; e < kNibOps * 128; e += kThreads) {
     const int op = e >> 7, q = (e >> 4) & 7, nv = e & 15;
     uint32_t w = 0;
@@ -265,6 +276,30 @@ __device__ __forceinline__ uint32_t finish_window(uint32_t state, bool vec, uint
 __device__ __forceinline__ uint32_t slot_fold(const char* lds, const Acc4& a) {
   return nib_apply(lds, kOpZ16, a.a0) ^ nib_apply(lds, kOpZ12, a.a1) ^ nib_apply(lds, kOpZ8, a.a2) ^
          nib_apply(lds, kOpZ4, a.a3);
+}
+
+// x * x^32 mod P ^ nxt through the byte tables of the 4-byte operator: four lookups and eight vector
+// instructions against eight lookups and some twenty for a nibble-table operator.  The four copies do not
+// remove bank conflicts (about three cycles per lookup on random bytes), which the saved instructions outweigh
+// for windows of a few KiB and less.  z4base = kZ4Off + 4 * (lane & 3).
+__device__ __forceinline__ uint32_t z4_step(const char* lds, uint32_t z4base, uint32_t x, uint32_t nxt) {
+  const uint32_t o0 = ((x & 0xffu) << 4) + z4base;
+  const uint32_t o1 = (__builtin_amdgcn_ubfe(x, 8, 8) << 4) + z4base;
+  const uint32_t o2 = (__builtin_amdgcn_ubfe(x, 16, 8) << 4) + z4base;
+  const uint32_t o3 = ((x >> 24) << 4) + z4base;
+  const uint32_t t0 = lds_u32(lds, o0), t1 = lds_u32(lds, o1 + 4096u), t2 = lds_u32(lds, o2 + 8192u),
+                 t3 = lds_u32(lds, o3 + 12288u);
+  return xor3(xor3(t0, t1, t2), t3, nxt);
+}
+// slot_fold as a Horner chain over the unit's four accumulators: (((a0 z + a1) z + a2) z + a3) z, z = x^32.
+__device__ __forceinline__ uint32_t slot_fold_chain(const char* lds, uint32_t z4base, const Acc4& a) {
+#ifdef OZCS_SLOT_NIBBLE  // A/B build: the nibble-table form
+  return slot_fold(lds, a);
+#endif
+  uint32_t x = z4_step(lds, z4base, a.a0, a.a1);
+  x = z4_step(lds, z4base, x, a.a2);
+  x = z4_step(lds, z4base, x, a.a3);
+  return z4_step(lds, z4base, x, 0u);
 }
 
 // Folds the accumulators of a wavefront's two rows.  The result, valid in lane 63, is the register a
@@ -457,8 +492,9 @@ __device__ __forceinline__ void subwave_pair(const char* lds, uint32_t lb01, uin
   // whose low i+1 bits are all ones (they take in the lane 2^i below).  That leaves the lanes below idle:
   // they advance row B's values in the same instruction stream, and the result moves up by one DPP shift.
   // Lanes outside that pattern end up with values nobody reads.
-  x = slot_fold(lds, a);
-  y = slot_fold(lds, b);
+  const uint32_t z4base = kZ4Off + 4u * (uint32_t)(sl & 3);
+  x = slot_fold_chain(lds, z4base, a);
+  y = slot_fold_chain(lds, z4base, b);
 #pragma unroll
   for (int i = 0; i < kLevels; i++) {
     const bool taker = (sl & ((2 << i) - 1)) == (2 << i) - 1;
@@ -645,7 +681,8 @@ __global__ __launch_bounds__(kThreads) void crc_flat_kernel(const CrcLaunch p) {
         absorb(lds, lb01, lb23, b, cb[k]);
       }
     }
-    uint32_t x = slot_fold(lds, a), y = slot_fold(lds, b);
+    const uint32_t z4base = kZ4Off + 4u * (uint32_t)(sl & 3);
+    uint32_t x = slot_fold_chain(lds, z4base, a), y = slot_fold_chain(lds, z4base, b);
 #pragma unroll
     for (int i = 0; i < kLevels; i++) {  // as in crc_subwave_kernel
       const bool taker = (sl & ((2 << i) - 1)) == (2 << i) - 1;

@@ -124,6 +124,15 @@ struct Md5 {
   }
 };
 
+// MD5 with whole 128-byte lines per loader step.  With 64-byte steps every line is touched by two consecutive
+// steps; when the chip is full of wavefronts the second touch often misses the L2 and the line comes in again
+// (rocprofv3: 1.24 x the input size fetched at 16 KiB windows).  128-byte steps fetch every line once and are
+// 2.5-4 % faster there, but slower when wavefronts are scarce and each runs a long chain alone on its SIMD
+// (2.45 against 3.04 TB/s at 1 MiB windows, 32 GiB), so the launcher picks by window count.
+struct Md5Lines : Md5 {
+  static constexpr int kStepBlocks = 2;
+};
+
 constexpr int kLanes = 64;
 // LDS row of one window slot: PB 64-byte blocks + 16 bytes of pad (80 or 144 bytes: the 128-bit stores of
 // the loader role and the 128-bit loads of the owner role are then both conflict-free).
@@ -567,6 +576,10 @@ __global__ __launch_bounds__(kSplitThreads) void sha256_split_jobs_kernel(const 
   if (valid && tid >= kSplitWindows) store_digest<Sha256>(out, h);
 }
 
+// Tuning override for experiments (read once): OZCS_MD5_LINES = 0 never, 1 always whole-line MD5 loader steps;
+// unset = by window count.
+const int g_md5_lines = getenv("OZCS_MD5_LINES") ? atoi(getenv("OZCS_MD5_LINES")) : -1;
+
 // Tuning override for experiments (read once): OZCS_SHA_SPLIT = 0 never, 1 always; unset = by window count.
 const int g_sha_split = getenv("OZCS_SHA_SPLIT") ? atoi(getenv("OZCS_SHA_SPLIT")) : -1;
 
@@ -597,8 +610,15 @@ hipError_t digest_launch(const DigestLaunch& p, int mode, int num_cus, hipStream
     if (mode == kModeCompute) digest_windows_kernel<Sha256, kModeCompute><<<grid, block, 0, stream>>>(p);
     else digest_windows_kernel<Sha256, kModeVerify><<<grid, block, 0, stream>>>(p);
   } else {
-    if (mode == kModeCompute) digest_windows_kernel<Md5, kModeCompute><<<grid, block, 0, stream>>>(p);
-    else digest_windows_kernel<Md5, kModeVerify><<<grid, block, 0, stream>>>(p);
+    // at least two wavefronts for every SIMD (4 per CU): whole-line loader steps
+    const bool lines = g_md5_lines < 0 ? blocks >= (uint64_t)num_cus * 8 : g_md5_lines != 0;
+    if (lines) {
+      if (mode == kModeCompute) digest_windows_kernel<Md5Lines, kModeCompute><<<grid, block, 0, stream>>>(p);
+      else digest_windows_kernel<Md5Lines, kModeVerify><<<grid, block, 0, stream>>>(p);
+    } else {
+      if (mode == kModeCompute) digest_windows_kernel<Md5, kModeCompute><<<grid, block, 0, stream>>>(p);
+      else digest_windows_kernel<Md5, kModeVerify><<<grid, block, 0, stream>>>(p);
+    }
   }
   return hipGetLastError();
 }

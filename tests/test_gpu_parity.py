@@ -526,6 +526,7 @@ def test_sha256_one_and_two_wavefront_forms(gpu, split):
     from conftest import ROOT
     e = dict(os.environ)
     e["OZCS_SHA_SPLIT"] = split
+    e["OZCS_MD5_LINES"] = split   # MD5's two loader forms (64-byte / whole-line steps) ride along
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "variant_check.py"), "11", "digests"], env=e,
                        capture_output=True, text=True, timeout=170)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
