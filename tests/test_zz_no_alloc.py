@@ -137,3 +137,33 @@ def test_noalloc_limits_and_trivial_inputs(gpu):
                                               out.data_ptr(), s))
     torch.cuda.synchronize()
     assert out.tolist() == [n - 1, 0]
+
+
+def test_noalloc_under_graph_capture(gpu):
+    """What the entry point is for: it only enqueues kernels, so it can be captured into a HIP graph (where
+    hipMalloc is not allowed) and replayed; every replay presets the verdict words it uses."""
+    torch, native, L = gpu
+    t, bpc, chunk_len, n_chunks = oracle.CRC32C, 16384, 131072, 40
+    wpc = chunk_len // bpc
+    host = oracle.splitmix64(77, n_chunks * chunk_len)
+    stored = b"".join(oracle.compute(t, bpc, host[c * chunk_len:(c + 1) * chunk_len]) for c in range(n_chunks))
+    d = torch.from_numpy(host.copy()).cuda()
+    d_exp = torch.from_numpy(np.frombuffer(stored, dtype=np.uint8).copy()).cuda()
+    out = torch.full((2,), 99, dtype=torch.int64, device="cuda")
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            native.check(L.ozcs_verify_device_noalloc(0, t, bpc, d.data_ptr(), chunk_len, n_chunks, chunk_len, d_exp.data_ptr(),
+                                                      wpc * 4, wpc, 0, out.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.current_stream().wait_stream(s)
+    for flips, want in (([], [-1, -1]), ([(33, 5 * bpc + 1), (12, 7 * bpc)], [12, 7]), ([(39, chunk_len - 1)], [39, 7]), ([], [-1, -1])):
+        bad = host.copy()
+        for c, o in flips:
+            bad[c * chunk_len + o] ^= 0x10
+        d.copy_(torch.from_numpy(bad))
+        out.fill_(99)
+        g.replay()
+        torch.cuda.synchronize()
+        assert out.tolist() == want
