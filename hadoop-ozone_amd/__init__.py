@@ -3,11 +3,12 @@ bytes-per-checksum window).
 
   native    ctypes view of the C-ABI HIP library (csrc/libozcs.so, include/ozone_checksum.h)
   checksum  host-side mirror of the reference interface: Checksum, ChecksumData,
-            OzoneChecksumException, ChecksumType (hadoop-hdds/common/.../ozone/common/)
+            OzoneChecksumException, ChecksumType (hadoop-hdds/common/.../ozone/common/), the ChunkInfo
+            record that carries ChecksumData on the wire, and the client configuration keys
   read_path the validator and boundary arithmetic of ChunkInputStream around the verify call
   scrubber  the datanode scrubber's per-chunk check (KeyValueContainerCheck.verifyChecksum), batched
 """
 from . import native  # noqa: F401
-from .checksum import (Checksum, ChecksumData, ChecksumType,  # noqa: F401
-                       OzoneChecksumException)
+from .checksum import (Checksum, ChecksumData, ChecksumType, ChunkInfo,  # noqa: F401
+                       OzoneChecksumException, OzoneClientConfig)
 from . import read_path, scrubber  # noqa: F401,E402

@@ -221,6 +221,113 @@ class ChecksumData:
         return ChecksumData(ChecksumType(t), bpc, sums)
 
 
+class ChunkInfo:
+    """The record that carries a chunk's ChecksumData from the client to the datanode and onto its disk:
+    hadoop-hdds/common/src/main/java/org/apache/hadoop/ozone/container/common/helpers/ChunkInfo.java:34-196, wire form
+    ContainerProtos.ChunkInfo (DatanodeClientProtocol.proto:366-372: chunkName = 1, offset = 2, len = 3,
+    repeated KeyValue metadata = 4, checksumData = 5; KeyValue :159-162)."""
+
+    def __init__(self, chunkName, offset, len):  # noqa: A002 - the reference's parameter name
+        self.chunkName = chunkName
+        self.offset = offset
+        self.len = len
+        self.checksumData = None
+        self.metadata = {}
+        self.readDataIntoSingleBuffer = False
+
+    def addMetadata(self, key, value):
+        if key in self.metadata:
+            raise IOError("This key already exists. Key " + key)  # ChunkInfo.java:72-79
+        self.metadata[key] = value
+
+    def getChunkName(self):
+        return self.chunkName
+
+    def getOffset(self):
+        return self.offset
+
+    def getLen(self):
+        return self.len
+
+    def getChecksumData(self):
+        return self.checksumData
+
+    def setChecksumData(self, cData):
+        self.checksumData = cData
+
+    def getMetadata(self):
+        return self.metadata
+
+    def getProtoBufMessage(self):
+        """Serialised ContainerProtos.ChunkInfo (ChunkInfo.java:108-133): fields in number order, metadata in key
+        order (a TreeMap), a missing ChecksumData written as the NONE message."""
+        name = self.chunkName.encode("utf-8")
+        out = bytearray()
+        out += b"\x0a" + _varint(len(name)) + name
+        out += b"\x10" + _varint(self.offset)
+        out += b"\x18" + _varint(self.len)
+        for k in sorted(self.metadata):
+            kb, vb = k.encode("utf-8"), self.metadata[k].encode("utf-8")
+            kv = b"\x0a" + _varint(len(kb)) + kb + b"\x12" + _varint(len(vb)) + vb
+            out += b"\x22" + _varint(len(kv)) + kv
+        cd = self.checksumData.getProtoBufMessage() if self.checksumData is not None else Checksum.getNoChecksumDataProto()
+        out += b"\x2a" + _varint(len(cd)) + cd
+        return bytes(out)
+
+    @staticmethod
+    def getFromProtoBuf(buf):
+        """Inverse of getProtoBufMessage (ChunkInfo.java:88-103)."""
+        if buf is None:
+            raise ValueError("info is null")
+        name = off = ln = cd = None
+        meta, pos, n = [], 0, len(buf)
+        while pos < n:
+            key, pos = _read_varint(buf, pos)
+            field, wt = key >> 3, key & 7
+            if wt == 0:
+                v, pos = _read_varint(buf, pos)
+                if field == 2:
+                    off = v
+                elif field == 3:
+                    ln = v
+            elif wt == 2:
+                size, pos = _read_varint(buf, pos)
+                body = bytes(buf[pos:pos + size])
+                pos += size
+                if field == 1:
+                    name = body.decode("utf-8")
+                elif field == 4:
+                    meta.append(_read_key_value(body))
+                elif field == 5:
+                    cd = ChecksumData.getFromProtoBuf(body)
+            else:
+                raise ValueError("unsupported wire type %d" % wt)
+        if name is None or off is None or ln is None or cd is None:
+            raise ValueError("required field missing")
+        info = ChunkInfo(name, off, ln)
+        for k, v in meta:
+            info.addMetadata(k, v)
+        info.setChecksumData(cd)
+        return info
+
+    def __str__(self):  # ChunkInfo.java:182-188 (the quote after chunkName= is not closed there either)
+        return "ChunkInfo{chunkName='%s, offset=%d, len=%d}" % (self.chunkName, self.offset, self.len)
+
+
+def _read_key_value(body):
+    k, v, pos = "", "", 0
+    while pos < len(body):
+        key, pos = _read_varint(body, pos)
+        size, pos = _read_varint(body, pos)
+        text = body[pos:pos + size].decode("utf-8")
+        pos += size
+        if key >> 3 == 1:
+            k = text
+        elif key >> 3 == 2:
+            v = text
+    return k, v
+
+
 def _varint(v):
     out = bytearray()
     while True:

@@ -287,6 +287,113 @@ class Checksum {
   int bytesPerChecksum_;
 };
 
+// The record that carries a chunk's ChecksumData from the client to the datanode and onto its disk
+// (hadoop-hdds/common/src/main/java/org/apache/hadoop/ozone/container/common/helpers/ChunkInfo.java:34-196); wire form
+// ContainerProtos.ChunkInfo (DatanodeClientProtocol.proto:366-372: chunkName = 1, offset = 2, len = 3, repeated
+// KeyValue metadata = 4, checksumData = 5; KeyValue :159-162).
+class ChunkInfo {
+ public:
+  ChunkInfo(std::string chunkName, long long offset, long long len)
+      : chunkName_(std::move(chunkName)), offset_(offset), len_(len), checksumData_(ChecksumType::NONE, 0), hasChecksum_(false) {}
+
+  void addMetadata(const std::string& key, const std::string& value) {  // ChunkInfo.java:72-79
+    if (!metadata_.emplace(key, value).second) throw std::runtime_error("This key already exists. Key " + key);
+  }
+  const std::string& getChunkName() const { return chunkName_; }
+  long long getOffset() const { return offset_; }
+  long long getLen() const { return len_; }
+  const ChecksumData& getChecksumData() const { return checksumData_; }
+  void setChecksumData(const ChecksumData& c) { checksumData_ = c; hasChecksum_ = true; }
+  const std::map<std::string, std::string>& getMetadata() const { return metadata_; }
+
+  // ChunkInfo.java:108-133: fields in number order, metadata in key order (a TreeMap), a missing ChecksumData
+  // written as the NONE message (Checksum.getNoChecksumDataProto, Checksum.java:295-298).
+  ByteString getProtoBufMessage() const {
+    ByteString out;
+    putBytes(out, 0x0a, chunkName_);
+    out.push_back(0x10); putVarint(out, (uint64_t)offset_);
+    out.push_back(0x18); putVarint(out, (uint64_t)len_);
+    for (const auto& kv : metadata_) {
+      ByteString m;
+      putBytes(m, 0x0a, kv.first);
+      putBytes(m, 0x12, kv.second);
+      putBytes(out, 0x22, m);
+    }
+    putBytes(out, 0x2a, (hasChecksum_ ? checksumData_ : ChecksumData(ChecksumType::NONE, 0)).getProtoBufMessage());
+    return out;
+  }
+
+  static ChunkInfo getFromProtoBuf(const ByteString& msg) {  // ChunkInfo.java:88-103
+    std::string name;
+    uint64_t off = 0, len = 0;
+    bool hasName = false, hasOff = false, hasLen = false, hasCd = false;
+    std::vector<std::pair<std::string, std::string>> meta;
+    ChecksumData cd(ChecksumType::NONE, 0);
+    size_t i = 0;
+    while (i < msg.size()) {
+      const uint64_t key = getVarint(msg, i);
+      const uint64_t field = key >> 3, wire = key & 7;
+      if (wire == 0) {
+        const uint64_t v = getVarint(msg, i);
+        if (field == 2) { off = v; hasOff = true; }
+        if (field == 3) { len = v; hasLen = true; }
+      } else if (wire == 2) {
+        const uint64_t n = getVarint(msg, i);
+        if (n > msg.size() - i) throw std::invalid_argument("ChunkInfo: truncated message");
+        const ByteString body = msg.substr(i, (size_t)n);
+        i += (size_t)n;
+        if (field == 1) { name = body; hasName = true; }
+        if (field == 4) {
+          std::string k, v;
+          size_t j = 0;
+          while (j < body.size()) {
+            const uint64_t kk = getVarint(body, j), sz = getVarint(body, j);
+            if (sz > body.size() - j) throw std::invalid_argument("ChunkInfo: truncated KeyValue");
+            ((kk >> 3) == 1 ? k : v) = body.substr(j, (size_t)sz);
+            j += (size_t)sz;
+          }
+          meta.emplace_back(k, v);
+        }
+        if (field == 5) { cd = ChecksumData::getFromProtoBuf(body); hasCd = true; }
+      } else {
+        throw std::invalid_argument("ChunkInfo: unsupported wire type");
+      }
+    }
+    if (!(hasName && hasOff && hasLen && hasCd)) throw std::invalid_argument("ChunkInfo: required field missing");
+    ChunkInfo info(name, (long long)off, (long long)len);
+    for (const auto& kv : meta) info.addMetadata(kv.first, kv.second);
+    info.setChecksumData(cd);
+    return info;
+  }
+
+  // ChunkInfo.toString() (:182-188; the quote after chunkName= is not closed there either)
+  std::string toString() const {
+    return "ChunkInfo{chunkName='" + chunkName_ + ", offset=" + std::to_string(offset_) + ", len=" + std::to_string(len_) + "}";
+  }
+
+ private:
+  static void putVarint(ByteString& o, uint64_t v) {
+    while (v >= 0x80) { o.push_back((char)(v | 0x80)); v >>= 7; }
+    o.push_back((char)v);
+  }
+  static void putBytes(ByteString& o, char tag, const ByteString& b) { o.push_back(tag); putVarint(o, b.size()); o += b; }
+  static uint64_t getVarint(const ByteString& m, size_t& i) {
+    uint64_t v = 0;
+    for (int shift = 0; shift < 64; shift += 7) {
+      if (i >= m.size()) throw std::invalid_argument("ChunkInfo: truncated varint");
+      const uint8_t b = (uint8_t)m[i++];
+      v |= (uint64_t)(b & 0x7f) << shift;
+      if (!(b & 0x80)) return v;
+    }
+    throw std::invalid_argument("ChunkInfo: varint too long");
+  }
+  std::string chunkName_;
+  long long offset_, len_;
+  ChecksumData checksumData_;
+  bool hasChecksum_;
+  std::map<std::string, std::string> metadata_;
+};
+
 // The three checksum keys of the client configuration group "ozone.client" (OzoneClientConfig.java:103-125) with
 // the validation of :143-151: checksum.type defaults to CRC32, bytes.per.checksum to 1MB and is raised to 16 KiB
 // (OzoneConfigKeys.java:340) with a warning when set lower, verify.checksum defaults to true.

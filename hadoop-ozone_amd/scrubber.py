@@ -95,6 +95,16 @@ def verifyChecksum(block_id, chunk_name, chunk_offset, chunk_len, checksum_data,
     return _replay(block_id, chunk_name, chunk_offset, chunk_len, checksum_data, data, first, throttler, canceler)
 
 
+def verifyChunkProto(block_id, chunk_proto, chunk_file, layout, throttler=None, canceler=None):
+    """verifyChecksum with the arguments the reference's function takes (KeyValueContainerCheck.java:262-267): the
+    chunk as a serialised ContainerProtos.ChunkInfo, from which name, offset, length and the stored ChecksumData are
+    read (:266-269, :305)."""
+    from .checksum import ChunkInfo
+    info = ChunkInfo.getFromProtoBuf(chunk_proto)
+    return verifyChecksum(block_id, info.getChunkName(), info.getOffset(), info.getLen(), info.getChecksumData(),
+                          chunk_file, layout, throttler, canceler)
+
+
 def verifyBlock(block_id, chunks, layout, throttler=None, canceler=None):
     """The `for chunk in block.getChunks()` loop of KeyValueContainerCheck.scanData (:235-257) with ONE
     ozcs_verify_batch call for all chunks instead of one checksum call per window.

@@ -121,6 +121,26 @@ int main() {
     } catch (const OzoneChecksumException& e) { EXPECT(e.index() == 1); }
   }
 
+  // ---- ChunkInfo wire form (ChunkInfo.java:88-133, DatanodeClientProtocol.proto:366-372) ----
+  {
+    const ChecksumData cd(ChecksumType::CRC32, 1 << 20, {ByteString("\x01\x02\x03\x04", 4), ByteString("\xff\xfe\xfd\xfc", 4)});
+    ChunkInfo info("105_chunk_3", 8ll << 20, 4ll << 20);
+    info.setChecksumData(cd);
+    info.addMetadata("zeta", "1");
+    info.addMetadata("alpha", "x");
+    try { info.addMetadata("alpha", "y"); EXPECT(!"duplicate key accepted"); } catch (const std::runtime_error&) {}
+    const ByteString cdm = cd.getProtoBufMessage();
+    ByteString want = ByteString("\x0a\x0b") + "105_chunk_3" + ByteString("\x10\x80\x80\x80\x04", 5) + ByteString("\x18\x80\x80\x80\x02", 5) +
+                      ByteString("\x22\x0a\x0a\x05") + "alpha" + ByteString("\x12\x01x") + ByteString("\x22\x09\x0a\x04") + "zeta" +
+                      ByteString("\x12\x01") + "1" + ByteString("\x2a") + ByteString(1, (char)cdm.size()) + cdm;
+    EXPECT(info.getProtoBufMessage() == want);
+    const ChunkInfo back = ChunkInfo::getFromProtoBuf(want);
+    EXPECT(back.getChunkName() == "105_chunk_3" && back.getOffset() == (8ll << 20) && back.getLen() == (4ll << 20));
+    EXPECT(back.getChecksumData() == cd && back.getMetadata().size() == 2 && back.getMetadata().at("alpha") == "x");
+    EXPECT(back.toString() == "ChunkInfo{chunkName='105_chunk_3, offset=8388608, len=4194304}");
+    EXPECT(ChunkInfo::getFromProtoBuf(ChunkInfo("c", 0, 0).getProtoBufMessage()).getChecksumData() == ChecksumData(ChecksumType::NONE, 0));
+  }
+
   // ---- client configuration keys (OzoneClientConfig.java:103-125, 143-151) ----
   {
     const OzoneClientConfig dflt;

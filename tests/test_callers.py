@@ -219,3 +219,24 @@ def test_scrubber_throttles_then_judges_and_stops_at_the_first_failure(tmp_path)
     with pytest.raises(OzoneChecksumException, match="checksum item 3 expected"):
         scrubber.verifyBlock("b", chunks, scrubber.FILE_PER_BLOCK, throttler, token)
     assert seen == [bpc] * 10 + [bpc] * 4          # all of chunk 0, chunk 1 up to its failing window, chunk 2 not at all
+
+
+@pytest.mark.gpu
+def test_scrubber_takes_the_chunk_as_its_wire_record(tmp_path):
+    # KeyValueContainerCheck.verifyChecksum receives ContainerProtos.ChunkInfo: name, offset, length and the stored
+    # ChecksumData all come out of the serialised record
+    from hadoop_ozone_amd import ChunkInfo
+    chunk_len, bpc, off = 3 * 16384 + 100, 16384, 70000
+    blob = oracle.splitmix64(812, off + chunk_len + 50).tobytes()
+    path = tmp_path / "3.block"
+    path.write_bytes(blob)
+    d = blob[off:off + chunk_len]
+    info = ChunkInfo("3_chunk_2", off, chunk_len)
+    info.setChecksumData(ChecksumData(ChecksumType.CRC32C, bpc, [oracle.compute(oracle.CRC32C, bpc, d[o:o + bpc]) for o in range(0, chunk_len, bpc)]))
+    msg = info.getProtoBufMessage()
+    assert scrubber.verifyChunkProto("blk3", msg, str(path), scrubber.FILE_PER_BLOCK) == chunk_len
+    raw = bytearray(blob)
+    raw[off + 2 * bpc + 1] ^= 2
+    path.write_bytes(bytes(raw))
+    with pytest.raises(OzoneChecksumException, match=r"chunk=ChunkInfo\{chunkName='3_chunk_2, offset=70000, len=49252\} checksum item 2 expected"):
+        scrubber.verifyChunkProto("blk3", msg, str(path), scrubber.FILE_PER_BLOCK)

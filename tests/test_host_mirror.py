@@ -119,3 +119,32 @@ def test_reference_list_iteration_trace():
     for n in range(1, 80):
         k = len(reference_list_windows([3] * n))
         assert k * (k - 1) // 2 + 1 >= n and (k == 1 or (k - 1) * (k - 2) // 2 + 1 < n)
+
+
+# ---- ChunkInfo: the record that carries ChecksumData on the wire (ChunkInfo.java:34-196)
+
+def test_chunk_info_wire_form_round_trip():
+    from hadoop_ozone_amd import ChunkInfo
+    cd = ChecksumData(ChecksumType.CRC32, 1 << 20, [b"\x01\x02\x03\x04", b"\xff\xfe\xfd\xfc"])
+    info = ChunkInfo("105_chunk_3", 8 << 20, 4 << 20)
+    info.setChecksumData(cd)
+    info.addMetadata("zeta", "1")
+    info.addMetadata("alpha", "x")
+    with pytest.raises(IOError, match="This key already exists. Key alpha"):
+        info.addMetadata("alpha", "y")
+    msg = info.getProtoBufMessage()
+    # field by field: chunkName(1, bytes) offset(2, varint) len(3, varint) metadata(4, KeyValue, key order) checksumData(5)
+    cdm = cd.getProtoBufMessage()
+    want = (b"\x0a\x0b105_chunk_3" + b"\x10\x80\x80\x80\x04" + b"\x18\x80\x80\x80\x02"
+            + b"\x22\x0a" + b"\x0a\x05alpha\x12\x01x" + b"\x22\x09" + b"\x0a\x04zeta\x12\x011"
+            + b"\x2a" + bytes([len(cdm)]) + cdm)
+    assert msg == want
+    back = ChunkInfo.getFromProtoBuf(msg)
+    assert (back.getChunkName(), back.getOffset(), back.getLen()) == ("105_chunk_3", 8 << 20, 4 << 20)
+    assert back.getChecksumData() == cd and back.getMetadata() == {"alpha": "x", "zeta": "1"}
+    assert str(back) == "ChunkInfo{chunkName='105_chunk_3, offset=8388608, len=4194304}"
+    # no ChecksumData set: the NONE message goes out (ChunkInfo.java:116-120)
+    bare = ChunkInfo.getFromProtoBuf(ChunkInfo("c", 0, 0).getProtoBufMessage())
+    assert bare.getChecksumData() == ChecksumData(ChecksumType.NONE, 0)
+    with pytest.raises(ValueError):
+        ChunkInfo.getFromProtoBuf(b"\x0a\x01c\x10\x00")   # required fields missing
