@@ -1,5 +1,5 @@
 #!/bin/bash
-# Copies the round-2 measurement summaries from gpurun_out/ into profiles/ (run here after
+# Copies the measurement summaries (files named r02_*) from gpurun_out/ into profiles/ (run here after
 # scripts/final_measure_r02.sh ran on the GPU box).
 set -eu
 for f in r02_configs.log r02_crc_window_sizes.log r02_pipeline_end_to_end.log r02_host_sync_calls.log r02_call_latency.log \

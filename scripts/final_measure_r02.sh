@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 record, one GPU: bench lines of every configuration, CRC window-size table, pipeline, per-call rates,
+# The full measurement record on one GPU: bench lines of every configuration, CRC window-size table, pipeline, per-call rates,
 # then rocprofv3 trace + PMC passes of the headline, the 16 KiB verify, the SHA-256 32 GiB and two small-window
 # configurations.  Output under gpurun_out/; scripts/collect_r02.sh copies the summaries into profiles/.
 set -u

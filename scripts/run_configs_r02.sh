@@ -1,5 +1,5 @@
 #!/bin/bash
-# The bench lines of the BASELINE configurations on one GPU, with their CPU baselines (round 2 record).
+# The bench lines of every benchmark configuration on one GPU, with their CPU baselines.
 set -u
 run() { echo "== bench.py $*"; timeout -k 10 400 python -u bench.py "$@" 2>/dev/null || exit 1; }
 run
