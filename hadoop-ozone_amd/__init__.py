@@ -7,8 +7,9 @@ bytes-per-checksum window).
             record that carries ChecksumData on the wire, and the client configuration keys
   read_path the validator and boundary arithmetic of ChunkInputStream around the verify call
   scrubber  the datanode scrubber's per-chunk check (KeyValueContainerCheck.verifyChecksum), batched
+  write_path  BlockOutputStream's chunking and ChunkInfo bookkeeping over the pinned pipe
 """
 from . import native  # noqa: F401
 from .checksum import (Checksum, ChecksumData, ChecksumType, ChunkInfo,  # noqa: F401
                        OzoneChecksumException, OzoneClientConfig)
-from . import read_path, scrubber  # noqa: F401,E402
+from . import read_path, scrubber, write_path  # noqa: F401,E402

@@ -240,3 +240,51 @@ def test_scrubber_takes_the_chunk_as_its_wire_record(tmp_path):
     path.write_bytes(bytes(raw))
     with pytest.raises(OzoneChecksumException, match=r"chunk=ChunkInfo\{chunkName='3_chunk_2, offset=70000, len=49252\} checksum item 2 expected"):
         scrubber.verifyChunkProto("blk3", msg, str(path), scrubber.FILE_PER_BLOCK)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("conf", [{}, {"ozone.client.checksum.type": "CRC32C", "ozone.client.bytes.per.checksum": "16KB"},
+                                  {"ozone.client.checksum.type": "MD5", "ozone.client.bytes.per.checksum": "256KB"},
+                                  {"ozone.client.checksum.type": "NONE"}],
+                         ids=["defaults", "crc32c-16k", "md5-256k", "none"])
+def test_write_path_like_TestBlockOutputStreamCorrectness(conf):
+    # TestBlockOutputStreamCorrectness.java: seeded random bytes written in odd pieces through BlockOutputStream with
+    # 4 MB buffers; what reaches writeChunkAsync must be the same bytes, cut into chunks of the buffer size, each with
+    # the ChunkInfo the reference builds (BlockOutputStream.java:645-656) -- here checksums included
+    from hadoop_ozone_amd import ChunkInfo, OzoneClientConfig
+    from hadoop_ozone_amd.write_path import BlockOutputStream
+    cfg = OzoneClientConfig(conf)
+    total = 6 * (1 << 20) + 12345
+    payload = oracle.splitmix64(2024, total).tobytes()
+    shipped = []
+    out = BlockOutputStream(777, lambda info, data: shipped.append((info, data)), cfg, streamBufferSize=1 << 20, capacity=3)
+    pos, k = 0, 0
+    while pos < total:   # writes of 1 B .. ~600 KiB that never line up with the buffers
+        n = min(total - pos, (1, 4099, 600001, 77, 262144)[k % 5])
+        out.write(payload, pos, n)
+        pos += n
+        k += 1
+    out.close()
+    assert out.getWrittenDataLength() == total
+    assert b"".join(d for _, d in shipped) == payload
+    assert [len(d) for _, d in shipped] == [1 << 20] * 6 + [12345]
+    t, bpc = cfg.getChecksumType(), cfg.getBytesPerChecksum()
+    off = 0
+    for i, (info, data) in enumerate(shipped):
+        assert (info.getChunkName(), info.getOffset(), info.getLen()) == ("777_chunk_%d" % (i + 1), off, len(data))
+        cd = info.getChecksumData()
+        assert (cd.getChecksumType(), cd.getBytesPerChecksum()) == (t, bpc)
+        ds = native_digest_size(t)
+        exp = oracle.compute(int(t), bpc, data) if t != ChecksumType.NONE else b""
+        assert b"".join(cd.getChecksums()) == exp and all(len(c) == ds for c in cd.getChecksums())
+        back = ChunkInfo.getFromProtoBuf(info.getProtoBufMessage())   # what goes into WriteChunkRequestProto.chunkData
+        assert back.getChecksumData() == cd and back.getOffset() == off
+        off += len(data)
+    assert out.chunks == [info for info, _ in shipped]
+    with pytest.raises(IOError):
+        out.write(b"x")
+
+
+def native_digest_size(t):
+    from hadoop_ozone_amd import native
+    return native.DIGEST_SIZE[int(t)]
