@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -629,6 +630,13 @@ int ozcs_init(uint32_t device_mask) {
     devs.push_back(d);
   }
   if (devs.empty()) return fail(OZCS_ENODEV, "no gfx950 device among %d HIP device(s)", n);
+  // Test hook (read at init): OZCS_TEST_REPLICATE_DEVICES = k lists every usable device k times, so that the
+  // multi-device code paths (sharding a batch over devices, one host thread per shard) run on a one-GPU machine.
+  if (const char* rep = getenv("OZCS_TEST_REPLICATE_DEVICES")) {
+    const int k = atoi(rep);
+    const std::vector<DeviceInfo> once = devs;
+    for (int r = 1; r < k && r < 8; r++) devs.insert(devs.end(), once.begin(), once.end());
+  }
   g.devs = devs;
   g.inited.store(true, std::memory_order_release);
   return OZCS_OK;

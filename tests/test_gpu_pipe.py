@@ -170,3 +170,13 @@ def test_pipe_refused_digest_launch_is_reported_by_its_tickets(gpu):
                        text=True, timeout=110)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "pipe fault check ok" in r.stdout
+
+
+def test_batch_calls_sharded_over_replicated_devices(gpu):
+    # the multi-device paths of ozcs_compute_batch / ozcs_verify_batch on a one-GPU box: the device is listed three times
+    e = dict(os.environ)
+    e["OZCS_TEST_REPLICATE_DEVICES"] = "3"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "multi_device_check.py")], env=e, capture_output=True,
+                       text=True, timeout=150)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "multi-device check ok" in r.stdout
