@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -101,6 +102,36 @@ __global__ __launch_bounds__(1024) void read_crc_pattern(const uint8_t* p, uint6
   if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = 1;
 }
 
+// the small-window CRC kernels' pattern: LPW lanes share a window (a load instruction gathers 64/LPW pieces of
+// 16*LPW bytes, one per window, `win` bytes apart), two rows of windows per wavefront, one stripe group ahead;
+// with LDS != 0 the workgroup also holds 154 KiB of LDS like the CRC kernels (one workgroup per CU)
+// SPREAD (odd): logical window g is physical window (g * SPREAD) mod nwin, nwin a power of two -- the windows one
+// wavefront reads together are then SPREAD windows apart instead of adjacent
+template <int LPW, int LDS, int SPREAD = 1>
+__global__ __launch_bounds__(1024) void read_flat_pattern(const uint8_t* p, uint64_t nwin, uint32_t win, uint32_t* out) {
+  __shared__ char lds[LDS ? 157696 : 16];
+  if (LDS && threadIdx.x == 0) lds[win & 15] = 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int kPerRow = 64 / LPW;
+  constexpr uint32_t kStripe = 16u * LPW;
+  const int sl = lane & (LPW - 1), grp = lane / LPW;
+  u32x4 acc = {0, 0, 0, 0};
+  for (uint64_t w0 = ((uint64_t)blockIdx.x * 16 + wave) * 2 * kPerRow; w0 < nwin; w0 += (uint64_t)gridDim.x * 16 * 2 * kPerRow) {
+    const uint64_t ga = w0 + grp, gb = w0 + kPerRow + grp;
+    const uint8_t* qa = p + (((ga < nwin ? ga : nwin - 1) * SPREAD) & (nwin - 1)) * win + 16 * sl;
+    const uint8_t* qb = p + (((gb < nwin ? gb : nwin - 1) * SPREAD) & (nwin - 1)) * win + 16 * sl;
+    u32x4 a = __builtin_nontemporal_load((gptr)qa), b = __builtin_nontemporal_load((gptr)qb);
+    for (uint32_t o = kStripe; o < win; o += kStripe) {
+      const u32x4 na = __builtin_nontemporal_load((gptr)(qa + o)), nb = __builtin_nontemporal_load((gptr)(qb + o));
+      acc ^= a ^ b;
+      a = na;
+      b = nb;
+    }
+    acc ^= a ^ b;
+  }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = lds[0];
+}
+
 // the same with ROWS 1 KiB rows per wavefront and stripe, and PF stripes ahead
 template <int G, int ROWS, int PF>
 __global__ __launch_bounds__(1024) void read_crc_rows(const uint8_t* p, uint64_t nwin, uint64_t win, uint32_t* out) {
@@ -180,6 +211,31 @@ int main(int argc, char** argv) {
   const uint64_t n16 = bytes / 16, win = 1 << 20, nwin = bytes / win;
   const u32x4* p = (const u32x4*)d;
   printf("buffer %llu GiB\n", (unsigned long long)(bytes >> 30));
+  if (argc > 2 && !strcmp(argv[2], "flat")) {   // bare reads in the small-window kernels' pattern, window size x lanes per window
+    for (uint32_t w : {512u, 4096u, 8192u, 16384u, 32768u, 65536u}) {
+      char name[96];
+      const uint64_t nw = bytes / w;
+      snprintf(name, sizeof name, "flat pattern %6u B windows,  8 lanes, LDS held", w);
+      timeit(name, bytes, [&] { read_flat_pattern<8, 1><<<256, 1024>>>(d, nw, w, out); });
+      snprintf(name, sizeof name, "flat pattern %6u B windows, 16 lanes, LDS held", w);
+      timeit(name, bytes, [&] { read_flat_pattern<16, 1><<<256, 1024>>>(d, nw, w, out); });
+      snprintf(name, sizeof name, "flat pattern %6u B windows, 32 lanes, LDS held", w);
+      timeit(name, bytes, [&] { read_flat_pattern<32, 1><<<256, 1024>>>(d, nw, w, out); });
+      snprintf(name, sizeof name, "flat pattern %6u B windows,  8 lanes, 2 workgroups per CU", w);
+      timeit(name, bytes, [&] { read_flat_pattern<8, 0><<<512, 1024>>>(d, nw, w, out); });
+      snprintf(name, sizeof name, "flat pattern %6u B windows,  8 lanes, windows 3 apart", w);
+      timeit(name, bytes, [&] { read_flat_pattern<8, 1, 3><<<256, 1024>>>(d, nw, w, out); });
+      snprintf(name, sizeof name, "flat pattern %6u B windows,  8 lanes, windows 17 apart", w);
+      timeit(name, bytes, [&] { read_flat_pattern<8, 1, 17><<<256, 1024>>>(d, nw, w, out); });
+      snprintf(name, sizeof name, "flat pattern %6u B windows,  8 lanes, windows 257 apart", w);
+      timeit(name, bytes, [&] { read_flat_pattern<8, 1, 257><<<256, 1024>>>(d, nw, w, out); });
+      snprintf(name, sizeof name, "flat pattern %6u B windows, 16 lanes, windows 17 apart", w);
+      timeit(name, bytes, [&] { read_flat_pattern<16, 1, 17><<<256, 1024>>>(d, nw, w, out); });
+      snprintf(name, sizeof name, "flat pattern %6u B windows, 32 lanes, windows 17 apart", w);
+      timeit(name, bytes, [&] { read_flat_pattern<32, 1, 17><<<256, 1024>>>(d, nw, w, out); });
+    }
+    return 0;
+  }
   timeit("gridstride 2048x256 unroll4", bytes, [&] { read_gridstride<4, false><<<2048, 256>>>(p, n16, out); });
   timeit("gridstride 2048x256 unroll8", bytes, [&] { read_gridstride<8, false><<<2048, 256>>>(p, n16, out); });
   timeit("gridstride 2048x256 unroll8 nt", bytes, [&] { read_gridstride<8, true><<<2048, 256>>>(p, n16, out); });
