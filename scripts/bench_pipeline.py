@@ -16,13 +16,13 @@ from hadoop_ozone_amd import native
 MIB = 1 << 20
 
 
-def run(L, n_slots, n_chunks, mix, staged, bpc=MIB, any_order=False):
+def run(L, n_slots, n_chunks, mix, staged, bpc=MIB, any_order=False, only=None):
     """any_order: a full pipe is relieved by whichever ticket completes first (many streams share the pipe, or the
     stream ships chunks as their digests arrive) instead of by the oldest ticket (one strictly ordered stream)."""
     pipe = ctypes.c_void_p()
     native.check(L.ozcs_pipe_create(0, n_slots, 4 * MIB, ctypes.byref(pipe)))
     src = np.random.default_rng(1).integers(0, 256, 4 * MIB, dtype=np.uint8)
-    cap = (4 * MIB // bpc) * 16
+    cap = (4 * MIB // bpc) * 32
     outs = [ctypes.create_string_buffer(cap) for _ in range(n_slots)]
     buf, ticket, n = ctypes.c_void_p(), ctypes.c_int(), ctypes.c_uint64()
     done_ticket = ctypes.c_int()
@@ -45,7 +45,7 @@ def run(L, n_slots, n_chunks, mix, staged, bpc=MIB, any_order=False):
     order = []
     t0 = time.perf_counter()
     for i in range(n_chunks):
-        t = native.MD5 if (mix and i % 4 == 3) else native.CRC32
+        t = only if only is not None else (native.MD5 if (mix and i % 4 == 3) else native.CRC32)
         if staged:
             while True:
                 rc = L.ozcs_pipe_submit(pipe, t, bpc, src.ctypes.data, 4 * MIB, outs[i % n_slots], cap, ctypes.byref(ticket))
@@ -88,6 +88,15 @@ def h2d_ceiling():
 def main():
     L = native.lib()
     native.check(L.ozcs_init(0))
+    if len(sys.argv) > 1 and sys.argv[1] == "digest-streams":   # one digest type only: what an MD5 or SHA-256 stream gets
+        for name, t in (("MD5", native.MD5), ("SHA256", native.SHA256)):
+            for bpc in (MIB, 16384):
+                for slots, any_order in ((64, False), (256, False), (256, True), (1024, True)):
+                    n = 1024 if (t == native.SHA256 and bpc == MIB) else 4096
+                    print(json.dumps({"types": name + " only", "bytes_per_checksum": bpc, "slots": slots,
+                                      "harvest": "any completed ticket" if any_order else "oldest ticket first",
+                                      "GBps": round(run(L, slots, n, False, False, bpc, any_order, only=t), 2)}), flush=True)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "mix":   # quick look: CRC32:MD5 3:1 at 1 MiB windows only
         for slots in (64, 128):
             print(json.dumps({"slots": slots, "any_order_GBps": round(run(L, slots, 4096, True, False, MIB, True), 2)}), flush=True)
