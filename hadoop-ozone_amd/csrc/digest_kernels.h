@@ -46,6 +46,11 @@ struct DigestJobList {
 };
 hipError_t digest_launch_jobs(const DigestJobList& p, int num_cus, hipStream_t stream);
 
+// The same with the job list in device-visible memory (sorted by first_window), for any number of chunks: the
+// pinned pipe hashes everything of one algorithm that has gathered in one launch.
+hipError_t digest_launch_jobs_mem(const DigestJob* d_jobs, uint32_t n_jobs, uint32_t n_windows, int algo, int num_cus,
+                                  hipStream_t stream);
+
 // SHA-256 / MD5 of n described windows (crc_kernels.h), the list in device memory: one lane per window.
 hipError_t digest_launch_desc(const WindowDesc* d_desc, uint32_t n, int algo, hipStream_t stream);
 

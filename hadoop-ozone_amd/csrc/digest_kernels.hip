@@ -576,6 +576,56 @@ __global__ __launch_bounds__(kSplitThreads) void sha256_split_jobs_kernel(const 
   if (valid && tid >= kSplitWindows) store_digest<Sha256>(out, h);
 }
 
+// The job-list kernels with the list in memory: the job of window g is found by bisection over first_window.
+__device__ __forceinline__ void job_window(const DigestJob* jobs, uint32_t n_jobs, uint32_t g, uint32_t digest_bytes,
+                                           uint64_t& start, uint32_t& len, uint8_t*& out) {
+  uint32_t lo = 0, hi = n_jobs;  // jobs[lo].first_window <= g < jobs[hi].first_window (hi == n_jobs: no bound)
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (jobs[mid].first_window <= g) lo = mid;
+    else hi = mid;
+  }
+  const DigestJob job = jobs[lo];
+  const uint64_t wi = g - job.first_window;
+  const uint64_t woff = wi * (uint64_t)job.bpc;
+  const uint64_t left = job.len - woff;
+  len = (uint32_t)(left < job.bpc ? left : job.bpc);
+  start = reinterpret_cast<uintptr_t>(job.data) + woff;
+  out = job.sums + wi * digest_bytes;
+}
+
+template <class H>
+__global__ __launch_bounds__(kLanes) void digest_jobs_mem_kernel(const DigestJob* jobs, uint32_t n_jobs, uint32_t n_windows) {
+  __shared__ __attribute__((aligned(16))) char stage[kLanes * row_bytes<H::kStepBlocks>()];
+  const int lane = threadIdx.x;
+  const uint32_t g = blockIdx.x * kLanes + lane;
+  const bool valid = g < n_windows;
+  uint64_t start = 0;
+  uint32_t len = 0;
+  uint8_t* out = nullptr;
+  if (valid) job_window(jobs, n_jobs, g, H::kWords * 4, start, len, out);
+  uint32_t h[H::kWords];
+  digest_core<H>(stage, lane, valid, start, len, h);
+  if (valid) store_digest<H>(out, h);
+}
+
+__global__ __launch_bounds__(kSplitThreads) void sha256_split_jobs_mem_kernel(const DigestJob* jobs, uint32_t n_jobs,
+                                                                              uint32_t n_windows) {
+  __shared__ __attribute__((aligned(16))) char stage[2 * kLanes * kRowBytes];
+  __shared__ __attribute__((aligned(16))) char wbuf[4 * kWBufBytes];
+  __shared__ uint32_t sync[4];
+  const int tid = threadIdx.x;
+  const uint32_t g = blockIdx.x * kSplitWindows + (tid & (kSplitWindows - 1));
+  const bool valid = g < n_windows;
+  uint64_t start = 0;
+  uint32_t len = 0;
+  uint8_t* out = nullptr;
+  if (valid) job_window(jobs, n_jobs, g, 32, start, len, out);
+  uint32_t h[8];
+  sha256_split_core(stage, wbuf, sync, tid, valid, start, len, h);
+  if (valid && tid >= kSplitWindows) store_digest<Sha256>(out, h);
+}
+
 // Tuning override for experiments (read once): OZCS_MD5_LINES = 0 never, 1 always whole-line MD5 loader steps;
 // unset = by window count.
 const int g_md5_lines = getenv("OZCS_MD5_LINES") ? atoi(getenv("OZCS_MD5_LINES")) : -1;
@@ -640,6 +690,20 @@ hipError_t digest_launch_jobs(const DigestJobList& p, int num_cus, hipStream_t s
   const dim3 grid((p.n_windows + kLanes - 1) / kLanes), block(kLanes);
   if (p.algo == kAlgoSha256) digest_jobs_kernel<Sha256><<<grid, block, 0, stream>>>(p);
   else digest_jobs_kernel<Md5><<<grid, block, 0, stream>>>(p);
+  return hipGetLastError();
+}
+
+hipError_t digest_launch_jobs_mem(const DigestJob* d_jobs, uint32_t n_jobs, uint32_t n_windows, int algo, int num_cus,
+                                  hipStream_t stream) {
+  if (n_windows == 0 || n_jobs == 0) return hipSuccess;
+  if (algo == kAlgoSha256 && use_sha_split(n_windows, num_cus)) {
+    sha256_split_jobs_mem_kernel<<<dim3((n_windows + kSplitWindows - 1) / kSplitWindows), dim3(kSplitThreads), 0, stream>>>(
+        d_jobs, n_jobs, n_windows);
+    return hipGetLastError();
+  }
+  const dim3 grid((n_windows + kLanes - 1) / kLanes), block(kLanes);
+  if (algo == kAlgoSha256) digest_jobs_mem_kernel<Sha256><<<grid, block, 0, stream>>>(d_jobs, n_jobs, n_windows);
+  else digest_jobs_mem_kernel<Md5><<<grid, block, 0, stream>>>(d_jobs, n_jobs, n_windows);
   return hipGetLastError();
 }
 

@@ -9,7 +9,7 @@
 // SHA-256 / MD5.  One lane hashes one window, so the windows of one chunk fill a few lanes of one wavefront
 // for as long as one window takes (about 11 ms for a 1 MiB MD5 window), and the chip has room for thousands
 // of such wavefronts side by side.  Digest slots are therefore parked after their copy and launched in
-// batches (one job-list launch per algorithm and batch) on a pool of low-priority digest streams: a batch
+// batches (one launch per batch, its job list read from pinned memory) on a pool of low-priority digest streams: a batch
 // starts as soon as a digest stream is idle, takes everything of its algorithm that has gathered by then, and
 // several batches run concurrently.  The digest streams are low-priority so that they get hardware queues of
 // their own (the runtime keeps a queue pool per priority) and a long digest kernel never sits in front of a
@@ -22,8 +22,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/ozone_checksum.h"
@@ -79,6 +81,10 @@ struct DigestStream {
   hipEvent_t done = nullptr;  // end of the batch running on this stream
   bool running = false;
   std::vector<int> slots;     // slots of that batch
+  DigestJob* h_jobs = nullptr;        // pinned, n_slots entries: the job list of that batch, read by the kernel in place
+  DigestJob* d_jobs_alias = nullptr;  // its device-side address
+  double launched_s = 0;              // when that batch was launched (host clock)
+  int algo = 0;
 };
 
 int make_ticket(int slot, uint32_t epoch) { return slot | (int)((epoch & kEpochMask) << kSlotBits); }
@@ -112,6 +118,10 @@ struct ozcs_pipe {
   size_t crc_head = 0;         // first live entry of crc_fifo
   uint32_t in_flight = 0;      // slots in kInFlight
   uint32_t done_unclaimed = 0; // slots in kDone
+  // pacing of digest batches (see launch_deferred): when the last batch was launched, and how long the last
+  // batch of each algorithm was seen to take
+  double last_launch_s = -1e9;
+  double batch_s[2] = {0, 0};
   std::mutex mu;
 };
 
@@ -120,6 +130,10 @@ namespace {
 // digests of a slot never exceed this: one 32-byte digest per 16 bytes would be absurd, so the pinned
 // digest buffer is sized for windows of at least 512 bytes and submit rejects what does not fit
 uint64_t sums_capacity(uint64_t slot_bytes) { return (slot_bytes / 512 + 1) * 32; }
+
+double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 // hipEventQuery that does not leave hipErrorNotReady behind as the thread's last error (the caller's own
 // HIP code would otherwise find it there).
@@ -176,38 +190,55 @@ void reap(ozcs_pipe* p) {
     for (int t : d.slots) mark_done(p, p->slots[t], status);
     d.slots.clear();
     d.running = false;
+    p->batch_s[d.algo] = now_s() - d.launched_s;
   }
 }
 
 // Launches parked digest slots on idle digest streams: per idle stream one batch of one algorithm (the one of
-// the oldest parked slot), up to kMaxDigestJobs chunks.  Slots that find no idle stream stay parked.  If the
-// runtime refuses a launch, every slot of that batch completes with the error (nothing was queued for it).
+// the oldest parked slot), however many chunks that is (the job list is read by the kernel from pinned memory).
+// Slots that find no idle stream stay parked.
+//
+// Pacing.  A batch lasts as long as its longest window whatever its size, so the slots a stream of chunks holds
+// are fewest when the K digest streams start their batches evenly spaced, each taking what gathered meanwhile.
+// Left to itself the pool does the opposite: one stream takes everything that has gathered, the next idle stream
+// starts a batch of one or two chunks right behind it and is then busy for a whole batch time.  So unless `force`
+// is set, a batch is started only when at least 1/K of the last observed batch time of that algorithm has
+// passed since the previous start, or when half of the slots are parked.  Callers that need a particular result
+// (ozcs_pipe_wait on a parked ticket) or find nothing else in flight to wait for pass force.
+//
+// If the runtime refuses a launch, every slot of that batch completes with the error (nothing was queued for it).
 // Caller holds p->mu, has selected the device and has called reap().
-int launch_deferred(ozcs_pipe* p) {
+int launch_deferred(ozcs_pipe* p, bool force = false) {
   int rc = OZCS_OK;
   for (DigestStream& d : p->digest) {
     if (p->deferred.empty()) break;
     if (d.running) continue;
     const int type = p->slots[p->deferred[0]].type;
-    DigestJobList jl{};
-    jl.algo = type == OZCS_SHA256 ? kAlgoSha256 : kAlgoMd5;
+    const int algo = type == OZCS_SHA256 ? kAlgoSha256 : kAlgoMd5;
+    const double now = now_s();
+    if (!force && p->deferred.size() * 2 < p->slots.size()) {
+      double gap = p->batch_s[algo] / (double)p->digest.size();
+      if (gap > 0.02) gap = 0.02;
+      if (now - p->last_launch_s < gap) break;
+    }
+    uint32_t n_jobs = 0, n_windows = 0;
     d.slots.clear();
     size_t keep = 0;
     int newest = -1;  // the batch's most recently submitted slot: copies are queued in submission order
     for (size_t i = 0; i < p->deferred.size(); i++) {
       const int t = p->deferred[i];
       Slot& s = p->slots[t];
-      if (s.type != type || jl.n_jobs == (uint32_t)kMaxDigestJobs) {
+      if (s.type != type || (uint64_t)n_windows + s.n_sums > 0x7fffffffull) {
         p->deferred[keep++] = t;
         continue;
       }
-      DigestJob& j = jl.jobs[jl.n_jobs++];
+      DigestJob& j = d.h_jobs[n_jobs++];
       j.data = s.d_data;
       j.len = s.len;
       j.sums = s.d_sums_alias;
       j.bpc = s.bpc;
-      j.first_window = jl.n_windows;
-      jl.n_windows += (uint32_t)s.n_sums;
+      j.first_window = n_windows;
+      n_windows += (uint32_t)s.n_sums;
       d.slots.push_back(t);
       newest = t;
     }
@@ -216,7 +247,7 @@ int launch_deferred(ozcs_pipe* p) {
     if (e == hipSuccess) {
       const int k = g_digest_launches.fetch_add(1, std::memory_order_relaxed) + 1;
       e = (g_fault_digest_launch && k == g_fault_digest_launch) ? hipErrorLaunchFailure
-                                                                : digest_launch_jobs(jl, p->dev.num_cus, d.stream);
+                                                                : digest_launch_jobs_mem(d.d_jobs_alias, n_jobs, n_windows, algo, p->dev.num_cus, d.stream);
     }
     if (e == hipSuccess) e = hipEventRecord(d.done, d.stream);
     if (e != hipSuccess) {
@@ -232,23 +263,43 @@ int launch_deferred(ozcs_pipe* p) {
       s.batch = (int)(&d - p->digest.data());
     }
     d.running = true;
+    d.launched_s = now;
+    d.algo = algo;
+    p->last_launch_s = now;
     s_launches.fetch_add(1, std::memory_order_relaxed);
-    s_windows.fetch_add(jl.n_windows, std::memory_order_relaxed);
+    s_windows.fetch_add(n_windows, std::memory_order_relaxed);
   }
   return rc;
 }
 
-// An event whose completion brings the pipe forward when nothing is done yet: the oldest CRC slot's, else a
-// running digest batch's (the one of `prefer` if it runs in one).  Null when no GPU work is queued at all.
+// An event whose completion brings the pipe forward when nothing is done yet: the oldest CRC slot's, else the
+// oldest running digest batch's (the one of `prefer` if it runs in one).  Null when no GPU work is queued at all.
 hipEvent_t progress_event(ozcs_pipe* p, const Slot* prefer) {
   if (prefer && prefer->state == kInFlight && !prefer->deferred) {
     if (prefer->batch >= 0) return p->digest[prefer->batch].done;
     return prefer->done;
   }
   if (p->crc_head < p->crc_fifo.size()) return p->slots[p->crc_fifo[p->crc_head]].done;
-  for (DigestStream& d : p->digest)
-    if (d.running) return d.done;
-  return nullptr;
+  const DigestStream* first = nullptr;  // the running batch that was launched first ends first
+  for (const DigestStream& d : p->digest)
+    if (d.running && (!first || d.launched_s < first->launched_s)) first = &d;
+  return first ? first->done : nullptr;
+}
+
+// Blocks the calling thread (without the pipe's lock) until `ev` has fired -- or, while digest slots are parked,
+// for a fraction of a millisecond only: a parked slot may be waiting for nothing but the pacing interval, and a
+// sleeping caller is often the only thread that would notice it has passed.  The caller re-evaluates afterwards.
+hipError_t wait_progress(ozcs_pipe* p, std::unique_lock<std::mutex>& lk, hipEvent_t ev) {
+  const bool parked = !p->deferred.empty();
+  lk.unlock();
+  hipError_t e = hipSuccess;
+  if (parked) {
+    std::this_thread::sleep_for(std::chrono::microseconds(200));
+  } else {
+    e = hipEventSynchronize(ev);
+  }
+  lk.lock();
+  return e;
 }
 
 void destroy_pipe(ozcs_pipe* p) {
@@ -264,6 +315,7 @@ void destroy_pipe(ozcs_pipe* p) {
   for (DigestStream& d : p->digest) {
     if (d.done) (void)hipEventDestroy(d.done);
     if (d.stream) (void)hipStreamDestroy(d.stream);
+    if (d.h_jobs) (void)hipHostFree(d.h_jobs);
   }
   if (p->h_data_all) (void)hipHostFree(p->h_data_all);
   if (p->d_data_all) (void)hipFree(p->d_data_all);
@@ -308,9 +360,9 @@ int finish(ozcs_pipe* p, int ticket, uint64_t* n_sums, bool block) {
     }
     if (s.state == kAcquired) return fail(OZCS_EINVAL, "ticket %d was never submitted", ticket);
     reap(p);
-    if (s.state == kInFlight && s.deferred) {
-      (void)launch_deferred(p);  // a failure is recorded in the slots it concerns
-    }
+    // a caller blocked on a parked ticket wants it now; otherwise parked slots start when the pacing allows
+    // (a failure is recorded in the slots it concerns)
+    if (!p->deferred.empty()) (void)launch_deferred(p, block && s.state == kInFlight && s.deferred);
     if (s.state == kDone) {
       const int status = s.status;
       if (n_sums) *n_sums = s.n_sums;
@@ -323,9 +375,7 @@ int finish(ozcs_pipe* p, int ticket, uint64_t* n_sums, bool block) {
     hipEvent_t ev = progress_event(p, &s);
     if (!ev) return fail(OZCS_EHIP, "ticket %d is in flight but no GPU work is queued", ticket);
     s.waiters++;
-    lk.unlock();
-    const hipError_t e = hipEventSynchronize(ev);
-    lk.lock();
+    const hipError_t e = wait_progress(p, lk, ev);
     s.waiters--;
     if (e != hipSuccess) {
       Slot* again = nullptr;
@@ -369,7 +419,7 @@ int ozcs_pipe_create(int device, uint32_t n_slots, uint64_t slot_bytes, ozcs_pip
     // so that parking, launching and queueing a slot later never allocate
     p->deferred.reserve(n_slots);
     p->crc_fifo.reserve((size_t)n_slots + 1024);
-    for (DigestStream& d : p->digest) d.slots.reserve(kMaxDigestJobs);
+    for (DigestStream& d : p->digest) d.slots.reserve(n_slots);
   } catch (...) {
     delete p;
     return fail(OZCS_ENOMEM, "out of host memory");
@@ -381,6 +431,8 @@ int ozcs_pipe_create(int device, uint32_t n_slots, uint64_t slot_bytes, ozcs_pip
   for (DigestStream& d : p->digest) {
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&d.stream, hipStreamNonBlocking, g_digest_low_prio ? prio_low : 0);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&d.done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&d.h_jobs), sizeof(DigestJob) * n_slots, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&d.d_jobs_alias), d.h_jobs, 0);
   }
   if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&p->h_data_all), stride * n_slots, hipHostMallocDefault);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_data_all), stride * n_slots);
@@ -540,10 +592,12 @@ int ozcs_pipe_next_completed(ozcs_pipe* p, int block, int* ticket, int* status, 
     if (p->in_flight == 0) return fail(OZCS_EEMPTY, "no submitted ticket is outstanding");
     if (!block) return OZCS_EBUSY;
     hipEvent_t ev = progress_event(p, nullptr);
+    if (!ev && !p->deferred.empty()) {  // only parked slots are left: nothing to wait for until they are launched
+      (void)launch_deferred(p, true);
+      continue;
+    }
     if (!ev) return fail(OZCS_EHIP, "tickets are in flight but no GPU work is queued");
-    lk.unlock();
-    const hipError_t e = hipEventSynchronize(ev);
-    lk.lock();
+    const hipError_t e = wait_progress(p, lk, ev);
     if (e != hipSuccess) return fail_hip(e, "pipe completion");
   }
 }
@@ -563,10 +617,12 @@ int ozcs_pipe_drain(ozcs_pipe* p) {
     }
     if (p->in_flight == 0) return rc;
     hipEvent_t ev = progress_event(p, nullptr);
+    if (!ev && !p->deferred.empty()) {  // only parked slots are left: nothing to wait for until they are launched
+      (void)launch_deferred(p, true);
+      continue;
+    }
     if (!ev) return fail(OZCS_EHIP, "tickets are in flight but no GPU work is queued");
-    lk.unlock();
-    const hipError_t e = hipEventSynchronize(ev);
-    lk.lock();
+    const hipError_t e = wait_progress(p, lk, ev);
     if (e != hipSuccess) return fail_hip(e, "pipe drain");
   }
 }

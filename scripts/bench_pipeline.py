@@ -92,7 +92,7 @@ def main():
         for name, t in (("MD5", native.MD5), ("SHA256", native.SHA256)):
             for bpc in (MIB, 16384):
                 for slots, any_order in ((64, False), (256, False), (256, True), (1024, True)):
-                    n = 1024 if (t == native.SHA256 and bpc == MIB) else 4096
+                    n = 8192 if slots >= 1024 else 4096
                     print(json.dumps({"types": name + " only", "bytes_per_checksum": bpc, "slots": slots,
                                       "harvest": "any completed ticket" if any_order else "oldest ticket first",
                                       "GBps": round(run(L, slots, n, False, False, bpc, any_order, only=t), 2)}), flush=True)
