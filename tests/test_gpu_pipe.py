@@ -180,3 +180,29 @@ def test_batch_calls_sharded_over_replicated_devices(gpu):
                        text=True, timeout=150)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "multi-device check ok" in r.stdout
+
+
+def test_pipe_large_digest_batches(gpu):
+    # hundreds of SHA-256 / MD5 chunks parked at once: one batch holds far more chunks than a kernel-argument job list
+    # could, and the kernel finds every window's chunk by bisection over ragged chunk sizes and window sizes
+    torch, native, L = gpu
+    n_slots = 300
+    pipe = ctypes.c_void_p()
+    native.check(L.ozcs_pipe_create(0, n_slots, 65536, ctypes.byref(pipe)))
+    try:
+        jobs = []
+        for rnd in range(2):
+            for i in range(n_slots):
+                t = (oracle.SHA256, oracle.MD5, oracle.MD5, oracle.CRC32C)[i % 4]
+                ln = 65536 - 97 * (i % 50) if i % 9 else 1 + i
+                bpc = (4096, 16384, 1000, 65536)[i % 4]
+                d = oracle.splitmix64(31000 + rnd * 1000 + i, ln)
+                out = ctypes.create_string_buffer(((ln + bpc - 1) // bpc) * native.DIGEST_SIZE[t])
+                tk = ctypes.c_int(-1)
+                native.check(L.ozcs_pipe_submit(pipe, t, bpc, d.ctypes.data, ln, out, len(out), ctypes.byref(tk)))
+                jobs.append((t, bpc, d, out))
+            native.check(L.ozcs_pipe_drain(pipe))
+        for k, (t, bpc, d, out) in enumerate(jobs):
+            assert out.raw == oracle.compute(t, bpc, d), k
+    finally:
+        L.ozcs_pipe_destroy(pipe)
