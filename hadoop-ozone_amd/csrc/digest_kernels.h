@@ -29,8 +29,9 @@ struct DigestLaunch {
 
 hipError_t digest_launch(const DigestLaunch& p, int mode, int num_cus, hipStream_t stream);
 
-// Unrelated chunks hashed by one launch (compute only); the list travels in the kernel arguments.
-constexpr int kMaxDigestJobs = 96;
+// Unrelated chunks hashed by one launch (compute only).  The job list lies in device-visible memory (device
+// memory, or pinned host memory through its device alias), sorted by first_window, and may hold any number of
+// chunks: the batched calls and the pinned pipe hash everything of one algorithm in one launch.
 struct DigestJob {
   const uint8_t* data;  // device pointer of the chunk
   uint64_t len;
@@ -38,18 +39,8 @@ struct DigestJob {
   uint32_t bpc;
   uint32_t first_window;  // index of the chunk's first window in the launch
 };
-struct DigestJobList {
-  DigestJob jobs[kMaxDigestJobs];
-  uint32_t n_jobs;
-  uint32_t n_windows;
-  int algo;
-};
-hipError_t digest_launch_jobs(const DigestJobList& p, int num_cus, hipStream_t stream);
-
-// The same with the job list in device-visible memory (sorted by first_window), for any number of chunks: the
-// pinned pipe hashes everything of one algorithm that has gathered in one launch.
-hipError_t digest_launch_jobs_mem(const DigestJob* d_jobs, uint32_t n_jobs, uint32_t n_windows, int algo, int num_cus,
-                                  hipStream_t stream);
+hipError_t digest_launch_jobs(const DigestJob* d_jobs, uint32_t n_jobs, uint32_t n_windows, int algo, int num_cus,
+                              hipStream_t stream);
 
 // SHA-256 / MD5 of n described windows (crc_kernels.h), the list in device memory: one lane per window.
 hipError_t digest_launch_desc(const WindowDesc* d_desc, uint32_t n, int algo, hipStream_t stream);

@@ -465,33 +465,6 @@ __global__ __launch_bounds__(kLanes) void digest_windows_kernel(const DigestLaun
   }
 }
 
-// Job list: up to kMaxDigestJobs unrelated chunks (own pointer, length, window size, output) in one launch,
-// so that a handful of windows per chunk still adds up to full wavefronts.
-template <class H>
-__global__ __launch_bounds__(kLanes) void digest_jobs_kernel(const DigestJobList p) {
-  __shared__ __attribute__((aligned(16))) char stage[kLanes * row_bytes<H::kStepBlocks>()];
-  const int lane = threadIdx.x;
-  const uint32_t g = blockIdx.x * kLanes + lane;
-  const bool valid = g < p.n_windows;
-  uint64_t start = 0;
-  uint32_t len = 0;
-  uint8_t* out = nullptr;
-  if (valid) {
-    uint32_t j = 0;
-    while (j + 1 < p.n_jobs && p.jobs[j + 1].first_window <= g) j++;
-    const DigestJob& job = p.jobs[j];
-    const uint64_t wi = g - job.first_window;
-    const uint64_t woff = wi * (uint64_t)job.bpc;
-    const uint64_t left = job.len - woff;
-    len = (uint32_t)(left < job.bpc ? left : job.bpc);
-    start = reinterpret_cast<uintptr_t>(job.data) + woff;
-    out = job.sums + wi * (H::kWords * 4);
-  }
-  uint32_t h[H::kWords];
-  digest_core<H>(stage, lane, valid, start, len, h);
-  if (valid) store_digest<H>(out, h);
-}
-
 // Windows given one by one (start, length, where the digest goes): any number of unrelated small chunks in one
 // launch, the list in device memory.
 template <class H>
@@ -550,33 +523,9 @@ __global__ __launch_bounds__(kSplitThreads) void sha256_split_windows_kernel(con
   }
 }
 
-__global__ __launch_bounds__(kSplitThreads) void sha256_split_jobs_kernel(const DigestJobList p) {
-  __shared__ __attribute__((aligned(16))) char stage[2 * kLanes * kRowBytes];
-  __shared__ __attribute__((aligned(16))) char wbuf[4 * kWBufBytes];
-  __shared__ uint32_t sync[4];
-  const int tid = threadIdx.x;
-  const uint32_t g = blockIdx.x * kSplitWindows + (tid & (kSplitWindows - 1));
-  const bool valid = g < p.n_windows;
-  uint64_t start = 0;
-  uint32_t len = 0;
-  uint8_t* out = nullptr;
-  if (valid) {
-    uint32_t j = 0;
-    while (j + 1 < p.n_jobs && p.jobs[j + 1].first_window <= g) j++;
-    const DigestJob& job = p.jobs[j];
-    const uint64_t wi = g - job.first_window;
-    const uint64_t woff = wi * (uint64_t)job.bpc;
-    const uint64_t left = job.len - woff;
-    len = (uint32_t)(left < job.bpc ? left : job.bpc);
-    start = reinterpret_cast<uintptr_t>(job.data) + woff;
-    out = job.sums + wi * 32;
-  }
-  uint32_t h[8];
-  sha256_split_core(stage, wbuf, sync, tid, valid, start, len, h);
-  if (valid && tid >= kSplitWindows) store_digest<Sha256>(out, h);
-}
-
-// The job-list kernels with the list in memory: the job of window g is found by bisection over first_window.
+// Job list: any number of unrelated chunks (own pointer, length, window size, output) in one launch, so that a
+// handful of windows per chunk still adds up to full wavefronts.  The list lies in device-visible memory,
+// sorted by first_window; the job of window g is found by bisection.
 __device__ __forceinline__ void job_window(const DigestJob* jobs, uint32_t n_jobs, uint32_t g, uint32_t digest_bytes,
                                            uint64_t& start, uint32_t& len, uint8_t*& out) {
   uint32_t lo = 0, hi = n_jobs;  // jobs[lo].first_window <= g < jobs[hi].first_window (hi == n_jobs: no bound)
@@ -595,7 +544,7 @@ __device__ __forceinline__ void job_window(const DigestJob* jobs, uint32_t n_job
 }
 
 template <class H>
-__global__ __launch_bounds__(kLanes) void digest_jobs_mem_kernel(const DigestJob* jobs, uint32_t n_jobs, uint32_t n_windows) {
+__global__ __launch_bounds__(kLanes) void digest_jobs_kernel(const DigestJob* jobs, uint32_t n_jobs, uint32_t n_windows) {
   __shared__ __attribute__((aligned(16))) char stage[kLanes * row_bytes<H::kStepBlocks>()];
   const int lane = threadIdx.x;
   const uint32_t g = blockIdx.x * kLanes + lane;
@@ -609,7 +558,7 @@ __global__ __launch_bounds__(kLanes) void digest_jobs_mem_kernel(const DigestJob
   if (valid) store_digest<H>(out, h);
 }
 
-__global__ __launch_bounds__(kSplitThreads) void sha256_split_jobs_mem_kernel(const DigestJob* jobs, uint32_t n_jobs,
+__global__ __launch_bounds__(kSplitThreads) void sha256_split_jobs_kernel(const DigestJob* jobs, uint32_t n_jobs,
                                                                               uint32_t n_windows) {
   __shared__ __attribute__((aligned(16))) char stage[2 * kLanes * kRowBytes];
   __shared__ __attribute__((aligned(16))) char wbuf[4 * kWBufBytes];
@@ -681,29 +630,17 @@ hipError_t digest_launch_desc(const WindowDesc* d_desc, uint32_t n, int algo, hi
   return hipGetLastError();
 }
 
-hipError_t digest_launch_jobs(const DigestJobList& p, int num_cus, hipStream_t stream) {
-  if (p.n_windows == 0 || p.n_jobs == 0) return hipSuccess;
-  if (p.algo == kAlgoSha256 && use_sha_split(p.n_windows, num_cus)) {
-    sha256_split_jobs_kernel<<<dim3((p.n_windows + kSplitWindows - 1) / kSplitWindows), dim3(kSplitThreads), 0, stream>>>(p);
-    return hipGetLastError();
-  }
-  const dim3 grid((p.n_windows + kLanes - 1) / kLanes), block(kLanes);
-  if (p.algo == kAlgoSha256) digest_jobs_kernel<Sha256><<<grid, block, 0, stream>>>(p);
-  else digest_jobs_kernel<Md5><<<grid, block, 0, stream>>>(p);
-  return hipGetLastError();
-}
-
-hipError_t digest_launch_jobs_mem(const DigestJob* d_jobs, uint32_t n_jobs, uint32_t n_windows, int algo, int num_cus,
+hipError_t digest_launch_jobs(const DigestJob* d_jobs, uint32_t n_jobs, uint32_t n_windows, int algo, int num_cus,
                                   hipStream_t stream) {
   if (n_windows == 0 || n_jobs == 0) return hipSuccess;
   if (algo == kAlgoSha256 && use_sha_split(n_windows, num_cus)) {
-    sha256_split_jobs_mem_kernel<<<dim3((n_windows + kSplitWindows - 1) / kSplitWindows), dim3(kSplitThreads), 0, stream>>>(
+    sha256_split_jobs_kernel<<<dim3((n_windows + kSplitWindows - 1) / kSplitWindows), dim3(kSplitThreads), 0, stream>>>(
         d_jobs, n_jobs, n_windows);
     return hipGetLastError();
   }
   const dim3 grid((n_windows + kLanes - 1) / kLanes), block(kLanes);
-  if (algo == kAlgoSha256) digest_jobs_mem_kernel<Sha256><<<grid, block, 0, stream>>>(d_jobs, n_jobs, n_windows);
-  else digest_jobs_mem_kernel<Md5><<<grid, block, 0, stream>>>(d_jobs, n_jobs, n_windows);
+  if (algo == kAlgoSha256) digest_jobs_kernel<Sha256><<<grid, block, 0, stream>>>(d_jobs, n_jobs, n_windows);
+  else digest_jobs_kernel<Md5><<<grid, block, 0, stream>>>(d_jobs, n_jobs, n_windows);
   return hipGetLastError();
 }
 

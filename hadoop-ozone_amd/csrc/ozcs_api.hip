@@ -316,6 +316,7 @@ constexpr uint64_t kSmallChunkWindows = 64;
 constexpr uint64_t kStagePiece = 8ull << 20;
 constexpr uint64_t kPinnedSumsMax = 32ull << 20;
 constexpr uint64_t kSplitCallBytes = 32ull << 20;  // ozcs_compute on at least this much goes through the batched path
+constexpr uint64_t kMaxLaunchWindows = 0x7fffffffull;  // window indices of a digest job launch are 32-bit
 constexpr size_t kGatherThreads = 4;
 constexpr uint64_t kGatherBytesPerThread = 8ull << 20;  // below 16 MiB of staged data one thread gathers
 
@@ -346,6 +347,10 @@ static void batch_on_device(int device, ozcs_chunk* chunks, uint32_t lo, uint32_
       const uint64_t n = ozcs_num_checksums(ch.len, ch.bpc);
       if (!ch.data || !ch.sums) { ch.status = fail(OZCS_EINVAL, "null pointer in chunk %u", j); continue; }
       if (ch.sums_cap < n * ds) { ch.status = fail(OZCS_EINVAL, "sums_cap too small in chunk %u", j); continue; }
+      if (n > kMaxLaunchWindows && (ch.type == OZCS_SHA256 || ch.type == OZCS_MD5)) {
+        ch.status = fail(OZCS_EINVAL, "chunk %u has more windows than one launch can number", j);
+        continue;
+      }
       if (!items.empty() && group_bytes + ch.len > kBatchStageBytes) break;
       items.push_back(Item{j, 0, 0, n, ds, ch.len <= kStagedChunkBytes, ch.len <= kSmallChunkBytes && n <= kSmallChunkWindows});
       group_bytes += (ch.len + 255) & ~(uint64_t)255;
@@ -353,16 +358,19 @@ static void batch_on_device(int device, ozcs_chunk* chunks, uint32_t lo, uint32_
     const uint32_t group_end = j;
     if (!items.empty()) {
       // ---- layout: staged chunks first (one contiguous region), then the others ----
-      uint64_t data_bytes = 0, sums_bytes = 0, n_desc = 0, staged_bytes = 0;
+      uint64_t data_bytes = 0, sums_bytes = 0, n_desc = 0, n_jobs = 0, staged_bytes = 0;
       for (int pass = 0; pass < 2; pass++) {
         for (Item& it : items) {
           if (it.staged != (pass == 0)) continue;
           it.data_off = data_bytes;
           data_bytes += (chunks[it.idx].len + 255) & ~(uint64_t)255;
           if (it.small) n_desc += it.n;
+          else if (chunks[it.idx].type == OZCS_SHA256 || chunks[it.idx].type == OZCS_MD5) n_jobs++;
         }
         if (pass == 0) staged_bytes = data_bytes;
       }
+      // the pinned staging buffer and the device's auxiliary buffer both hold: window descriptors, then digest jobs
+      const uint64_t desc_bytes = n_desc * sizeof(WindowDesc), aux_bytes = desc_bytes + n_jobs * sizeof(DigestJob);
       for (Item& it : items) {
         it.sums_off = sums_bytes;
         sums_bytes += it.small ? ((it.n * it.ds + 31) & ~(uint64_t)31) : ((it.n * it.ds + 255) & ~(uint64_t)255);
@@ -370,8 +378,8 @@ static void batch_on_device(int device, ozcs_chunk* chunks, uint32_t lo, uint32_
       const bool pinned_sums = sums_bytes <= kPinnedSumsMax;
       int rc = ctx_reserve(&c->d_data, &c->data_cap, data_bytes);
       if (rc == OZCS_OK) rc = ctx_reserve(&c->d_sums, &c->sums_cap, sums_bytes);
-      if (rc == OZCS_OK && n_desc) rc = ctx_reserve(&c->d_aux, &c->aux_cap, n_desc * sizeof(WindowDesc));
-      if (rc == OZCS_OK && staged_bytes) rc = host_reserve(&c->h_stage, &c->h_stage_cap, staged_bytes + n_desc * sizeof(WindowDesc));
+      if (rc == OZCS_OK && aux_bytes) rc = ctx_reserve(&c->d_aux, &c->aux_cap, aux_bytes);
+      if (rc == OZCS_OK && staged_bytes + aux_bytes) rc = host_reserve(&c->h_stage, &c->h_stage_cap, staged_bytes + aux_bytes);
       if (rc == OZCS_OK && pinned_sums) rc = host_reserve(&c->h_sums, &c->h_sums_cap, sums_bytes);
       hipError_t e = hipSuccess;
       uint8_t* dd = static_cast<uint8_t*>(c->d_data);
@@ -433,7 +441,7 @@ static void batch_on_device(int device, ozcs_chunk* chunks, uint32_t lo, uint32_
       }
       if (rc == OZCS_OK && n_desc) {
         // ---- descriptors of the small chunks' windows, grouped by checksum type ----
-        WindowDesc* hd = reinterpret_cast<WindowDesc*>(static_cast<uint8_t*>(c->h_stage) + staged_bytes);
+        WindowDesc* hd = reinterpret_cast<WindowDesc*>(static_cast<uint8_t*>(c->h_stage) + staged_bytes);  // 256-aligned
         WindowDesc* ddsc = static_cast<WindowDesc*>(c->d_aux);
         uint64_t first[5] = {0, 0, 0, 0, 0}, bytes[4] = {0, 0, 0, 0};
         uint64_t k = 0;
@@ -455,7 +463,7 @@ static void batch_on_device(int device, ozcs_chunk* chunks, uint32_t lo, uint32_
         }
         first[4] = k;
         if (e == hipSuccess)
-          e = hipMemcpyAsync(ddsc, hd, n_desc * sizeof(WindowDesc), hipMemcpyHostToDevice, c->stream);
+          e = hipMemcpyAsync(ddsc, hd, desc_bytes, hipMemcpyHostToDevice, c->stream);
         for (int t = 0; t < 4 && e == hipSuccess; t++) {
           const uint64_t nw = first[t + 1] - first[t];
           if (!nw) continue;
@@ -470,33 +478,40 @@ static void batch_on_device(int device, ozcs_chunk* chunks, uint32_t lo, uint32_
       for (const Item& it : items)
         if (!it.staged && rc == OZCS_OK && e == hipSuccess)
           e = hipMemcpyAsync(dd + it.data_off, chunks[it.idx].data, chunks[it.idx].len, hipMemcpyHostToDevice, c->stream);
-      for (int algo = 0; algo < 2 && rc == OZCS_OK && e == hipSuccess; algo++) {
-        const int type = algo == kAlgoSha256 ? OZCS_SHA256 : OZCS_MD5;
-        DigestJobList jl{};
-        jl.algo = algo;
-        auto launch = [&]() {
-          if (jl.n_jobs && e == hipSuccess) {
-            e = digest_launch_jobs(jl, dev->num_cus, c->stream);
-            s_launches.fetch_add(1, std::memory_order_relaxed);
-            s_windows.fetch_add(jl.n_windows, std::memory_order_relaxed);
+      if (rc == OZCS_OK && e == hipSuccess && n_jobs) {
+        // one job per chunk, grouped by algorithm; each group is one launch (more only where the windows of a
+        // group pass what a launch can number)
+        DigestJob* hj = reinterpret_cast<DigestJob*>(static_cast<uint8_t*>(c->h_stage) + staged_bytes + desc_bytes);
+        const DigestJob* dj = reinterpret_cast<const DigestJob*>(static_cast<const uint8_t*>(c->d_aux) + desc_bytes);
+        struct Run { uint32_t first, n_jobs, n_windows; int algo; };
+        std::vector<Run> runs;
+        uint32_t k = 0;
+        for (int algo = 0; algo < 2; algo++) {
+          const int type = algo == kAlgoSha256 ? OZCS_SHA256 : OZCS_MD5;
+          Run run{k, 0, 0, algo};
+          for (const Item& it : items) {
+            const ozcs_chunk& ch = chunks[it.idx];
+            if (it.small || ch.type != type) continue;
+            if ((uint64_t)run.n_windows + it.n > kMaxLaunchWindows) {
+              if (run.n_jobs) runs.push_back(run);
+              run = Run{k, 0, 0, algo};
+            }
+            hj[k] = DigestJob{dd + it.data_off, ch.len, dsums + it.sums_off, ch.bpc, run.n_windows};
+            k++;
+            run.n_jobs++;
+            run.n_windows += (uint32_t)it.n;
+            s_bytes.fetch_add(ch.len, std::memory_order_relaxed);
           }
-          jl.n_jobs = 0;
-          jl.n_windows = 0;
-        };
-        for (const Item& it : items) {
-          const ozcs_chunk& ch = chunks[it.idx];
-          if (it.small || ch.type != type) continue;
-          if (jl.n_jobs == (uint32_t)kMaxDigestJobs || (uint64_t)jl.n_windows + it.n > 0x7fffffffull) launch();
-          DigestJob& job = jl.jobs[jl.n_jobs++];
-          job.data = dd + it.data_off;
-          job.len = ch.len;
-          job.sums = dsums + it.sums_off;
-          job.bpc = ch.bpc;
-          job.first_window = jl.n_windows;
-          jl.n_windows += (uint32_t)it.n;
-          s_bytes.fetch_add(ch.len, std::memory_order_relaxed);
+          if (run.n_jobs) runs.push_back(run);
         }
-        launch();
+        e = hipMemcpyAsync(static_cast<uint8_t*>(c->d_aux) + desc_bytes, hj, n_jobs * sizeof(DigestJob),
+                           hipMemcpyHostToDevice, c->stream);
+        for (const Run& run : runs) {
+          if (e != hipSuccess) break;
+          e = digest_launch_jobs(dj + run.first, run.n_jobs, run.n_windows, run.algo, dev->num_cus, c->stream);
+          s_launches.fetch_add(1, std::memory_order_relaxed);
+          s_windows.fetch_add(run.n_windows, std::memory_order_relaxed);
+        }
       }
       for (const Item& it : items) {
         const ozcs_chunk& ch = chunks[it.idx];

@@ -247,7 +247,7 @@ int launch_deferred(ozcs_pipe* p, bool force = false) {
     if (e == hipSuccess) {
       const int k = g_digest_launches.fetch_add(1, std::memory_order_relaxed) + 1;
       e = (g_fault_digest_launch && k == g_fault_digest_launch) ? hipErrorLaunchFailure
-                                                                : digest_launch_jobs_mem(d.d_jobs_alias, n_jobs, n_windows, algo, p->dev.num_cus, d.stream);
+                                                                : digest_launch_jobs(d.d_jobs_alias, n_jobs, n_windows, algo, p->dev.num_cus, d.stream);
     }
     if (e == hipSuccess) e = hipEventRecord(d.done, d.stream);
     if (e != hipSuccess) {
