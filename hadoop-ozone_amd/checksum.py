@@ -12,6 +12,7 @@ import ctypes
 import enum
 
 from . import native
+from .chunk_buffer import ByteBuffer, ChunkBuffer
 
 
 class ChecksumType(enum.IntEnum):
@@ -376,6 +377,7 @@ class Checksum:
         bit for bit: only the elements reference_list_windows() names are checksummed (three of four, 24 of 256).
 
         data: bytes-like (byte[] / ByteBuffer overloads; off/length as in computeChecksum(byte[],int,int)),
+        a chunk_buffer.ByteBuffer or ChunkBuffer (windows as its iterate(bytesPerChecksum) cuts them),
         or a list of bytes-like (the List<ByteString> / ChunkBuffer-of-list overloads, one element per
         window; an element longer than bytesPerChecksum contributes only its first bytesPerChecksum
         bytes, Checksum.java:186-198 over ChunkBufferImplWithByteBufferList.java:180-204)."""
@@ -390,6 +392,10 @@ class Checksum:
         bpc = self.bytesPerChecksum
         if bpc <= 0:
             raise ValueError("bytesPerChecksum must be positive")  # ChunkBuffer.iterate rejects it
+        if isinstance(data, ByteBuffer):  # :140-146 (the read-only view changes nothing here)
+            data = ChunkBuffer.wrap(data)
+        if isinstance(data, ChunkBuffer):
+            return ChecksumData(ct, bpc, self._compute_windows(int(ct), bpc, ds, data))
         if isinstance(data, (list, tuple)):
             if reference_list_quirk:
                 data = [data[i] for i in reference_list_windows([len(memoryview(b).cast("B")) for b in data])]
@@ -400,6 +406,27 @@ class Checksum:
         if len(mv) == 0:
             return ChecksumData(ct, bpc, [])
         return ChecksumData(ct, bpc, _split(native.compute(int(ct), bpc, mv), ds))
+
+    # what Algorithm.newChecksumFunction() returns for a buffer with nothing remaining: the CRC register after
+    # reset() (Checksum.java:70-74), MessageDigest.digest() of no input (:55-59)
+    _EMPTY_DIGEST = {
+        int(ChecksumType.CRC32): bytes(4),
+        int(ChecksumType.CRC32C): bytes(4),
+        int(ChecksumType.SHA256): bytes.fromhex("e3b0c44298fc1c149afbf4c8996fb92427ae41e4649b934ca495991b7852b855"),
+        int(ChecksumType.MD5): bytes.fromhex("d41d8cd98f00b204e9800998ecf8427e"),
+    }
+
+    @classmethod
+    def _compute_windows(cls, t, bpc, ds, chunkBuffer):
+        """computeChecksum(ChunkBuffer), Checksum.java:155-177: one digest per buffer data.iterate(bytesPerChecksum)
+        yields, each over at most bytesPerChecksum bytes from the buffer's position (:186-198).  The iteration
+        runs first (it moves the ChunkBuffer's position as in the reference); then all windows go to the GPU in
+        one call.  A buffer with nothing remaining -- IncrementalChunkBuffer hands out its buffers as they are,
+        consumed ones included -- gets the digest of the empty message, as the reference's function yields."""
+        windows = [b.view()[:bpc] for b in chunkBuffer.iterate(bpc)]
+        filled = [w for w in windows if len(w)]
+        sums = iter(cls._compute_list(t, bpc, ds, filled))
+        return [next(sums) if len(w) else cls._EMPTY_DIGEST[t] for w in windows]
 
     @staticmethod
     def _compute_list(t, bpc, ds, buffers):

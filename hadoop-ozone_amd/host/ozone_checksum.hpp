@@ -5,6 +5,7 @@
 //   ChecksumData             .../ozone/common/ChecksumData.java:34-192
 //   OzoneChecksumException   .../ozone/common/OzoneChecksumException.java:29-66
 //   ChecksumType             hadoop-hdds/interface-client/src/main/proto/DatanodeClientProtocol.proto:384-390
+// (ChunkBuffer and its implementations: ozone_chunk_buffer.hpp.)
 // Every digest is computed by the GPU library; nothing here hashes on the CPU.  Header-only; link libozcs.so.
 #pragma once
 #include <cstdint>
@@ -17,6 +18,7 @@
 #include <vector>
 
 #include "../../include/ozone_checksum.h"
+#include "ozone_chunk_buffer.hpp"
 
 namespace ozone {
 
@@ -216,30 +218,32 @@ class Checksum {
       for (size_t i : referenceListWindows(lengths)) subset.push_back(all[i]);
     }
     const std::vector<ByteString>& byteStrings = referenceListQuirk ? subset : all;
-    if (checksumType_ == ChecksumType::NONE) return ChecksumData(checksumType_, bytesPerChecksum_);
-    const int t = (int)checksumType_;
-    if (t < OZCS_NONE || t > OZCS_MD5) throw OzoneChecksumException(checksumType_);
-    if (bytesPerChecksum_ <= 0) throw std::invalid_argument("bytesPerChecksum must be positive");
-    const size_t ds = ozcs_digest_size(t);
-    std::vector<ozcs_chunk> jobs;
-    std::vector<ByteString> outs;
+    std::vector<std::pair<const void*, size_t>> windows;
     for (const ByteString& b : byteStrings)
-      if (!b.empty()) outs.emplace_back(ds, '\0');
-    size_t k = 0;
-    for (const ByteString& b : byteStrings) {
-      if (b.empty()) continue;
-      ozcs_chunk c{};
-      c.data = b.data();
-      c.len = b.size() < (size_t)bytesPerChecksum_ ? b.size() : (size_t)bytesPerChecksum_;
-      c.sums = &outs[k][0];
-      c.sums_cap = ds;
-      c.bpc = (uint32_t)bytesPerChecksum_;
-      c.type = t;
-      jobs.push_back(c);
-      k++;
+      if (!b.empty()) windows.emplace_back(b.data(), b.size());  // empty elements yield nothing to iterate over
+    return computeWindows(windows);
+  }
+
+  // computeChecksum(ChunkBuffer), Checksum.java:155-177: one digest per buffer data.iterate(bytesPerChecksum)
+  // yields, each over at most bytesPerChecksum bytes from the buffer's position (:186-198).  The iteration runs
+  // first (it moves the ChunkBuffer's position as in the reference); then all windows go to the GPU in one call.
+  // A buffer with nothing remaining -- IncrementalChunkBuffer hands out its buffers as they are, consumed ones
+  // included -- gets the digest of the empty message, as the reference's function yields.
+  ChecksumData computeChecksum(ChunkBuffer& data) const {
+    if (checksumType_ == ChecksumType::NONE) return ChecksumData(checksumType_, bytesPerChecksum_);
+    if (bytesPerChecksum_ <= 0) throw std::invalid_argument("bytesPerChecksum must be positive");
+    std::vector<ByteBufferPtr> keep;
+    std::vector<std::pair<const void*, size_t>> windows;
+    for (ByteBufferIterator it = data.iterate(bytesPerChecksum_); it.hasNext();) {
+      keep.push_back(it.next());
+      windows.emplace_back(keep.back()->data(), (size_t)keep.back()->remaining());
     }
-    if (!jobs.empty()) check(ozcs_compute_batch(jobs.data(), (uint32_t)jobs.size()));
-    return ChecksumData(checksumType_, bytesPerChecksum_, outs);
+    return computeWindows(windows);
+  }
+  // computeChecksum(ByteBuffer), :140-146.
+  ChecksumData computeChecksum(const ByteBufferPtr& data) const {
+    ChunkBufferPtr wrapped = ChunkBuffer::wrap(data->asReadOnlyBuffer());
+    return computeChecksum(*wrapped);
   }
 
   // verifyChecksum(ByteString, ChecksumData, int) / (byte[], ChecksumData): Checksum.java:210-250.
@@ -276,6 +280,44 @@ class Checksum {
   static void check(int rc) {
     if (rc == OZCS_OK) return;
     throw GpuUnavailable(rc, std::string("ozcs error ") + std::to_string(rc) + ": " + ozcs_last_error());
+  }
+  // One digest per window, each clamped to bytesPerChecksum bytes; all filled windows in one batched call.
+  ChecksumData computeWindows(const std::vector<std::pair<const void*, size_t>>& windows) const {
+    if (checksumType_ == ChecksumType::NONE) return ChecksumData(checksumType_, bytesPerChecksum_);
+    const int t = (int)checksumType_;
+    if (t < OZCS_NONE || t > OZCS_MD5) throw OzoneChecksumException(checksumType_);
+    if (bytesPerChecksum_ <= 0) throw std::invalid_argument("bytesPerChecksum must be positive");
+    const size_t ds = ozcs_digest_size(t);
+    std::vector<ByteString> outs(windows.size(), ByteString(ds, '\0'));
+    std::vector<ozcs_chunk> jobs;
+    for (size_t i = 0; i < windows.size(); i++) {
+      if (windows[i].second == 0) {
+        outs[i] = emptyDigest(checksumType_);
+        continue;
+      }
+      ozcs_chunk c{};
+      c.data = windows[i].first;
+      c.len = windows[i].second < (size_t)bytesPerChecksum_ ? windows[i].second : (size_t)bytesPerChecksum_;
+      c.sums = &outs[i][0];
+      c.sums_cap = ds;
+      c.bpc = (uint32_t)bytesPerChecksum_;
+      c.type = t;
+      jobs.push_back(c);
+    }
+    if (!jobs.empty()) check(ozcs_compute_batch(jobs.data(), (uint32_t)jobs.size()));
+    return ChecksumData(checksumType_, bytesPerChecksum_, outs);
+  }
+  // What Algorithm.newChecksumFunction() returns for a buffer with nothing remaining: the CRC register after
+  // reset() (Checksum.java:70-74), MessageDigest.digest() of no input (:55-59).
+  static ByteString emptyDigest(ChecksumType type) {
+    static const unsigned char sha[32] = {0xe3, 0xb0, 0xc4, 0x42, 0x98, 0xfc, 0x1c, 0x14, 0x9a, 0xfb, 0xf4, 0xc8, 0x99, 0x6f, 0xb9, 0x24,
+                                          0x27, 0xae, 0x41, 0xe4, 0x64, 0x9b, 0x93, 0x4c, 0xa4, 0x95, 0x99, 0x1b, 0x78, 0x52, 0xb8, 0x55};
+    static const unsigned char md5[16] = {0xd4, 0x1d, 0x8c, 0xd9, 0x8f, 0x00, 0xb2, 0x04, 0xe9, 0x80, 0x09, 0x98, 0xec, 0xf8, 0x42, 0x7e};
+    switch (type) {
+      case ChecksumType::SHA256: return ByteString(reinterpret_cast<const char*>(sha), 32);
+      case ChecksumType::MD5: return ByteString(reinterpret_cast<const char*>(md5), 16);
+      default: return ByteString(4, '\0');
+    }
   }
   static std::vector<ByteString> split(const std::string& raw, size_t ds, uint64_t n) {
     std::vector<ByteString> v;

@@ -264,6 +264,57 @@ int main() {
     }
     EXPECT(checked == 10);
   }
+  // computeChecksum(ChunkBuffer) over the three implementations (Checksum.java:155-177 over ChunkBuffer.iterate)
+  for (ChecksumType t : types) {
+    const int n = 100000, bpc = 16384;
+    std::string bytes((size_t)n, '\0');
+    oracle_fill_splitmix64(97, (uint8_t*)&bytes[0], bytes.size());
+    const std::vector<ByteString> want = oracle_sums(t, bpc, bytes);
+    Checksum ck(t, bpc);
+    ChunkBufferPtr one = ChunkBuffer::allocate(n);
+    one->put(bytes);
+    ChunkBufferPtr dup = one->duplicate(0, one->position());
+    EXPECT(ck.computeChecksum(*dup).getChecksums() == want);
+    EXPECT(dup->position() == n && dup->limit() == n);   // "upon the iteration complete, position == limit"
+    EXPECT(ck.computeChecksum(ByteBuffer::wrapReadOnly(bytes.data(), bytes.size())).getChecksums() == want);
+    ChunkBufferPtr mid = one->duplicate(bpc, 70000);
+    EXPECT(ck.computeChecksum(*mid).getChecksums() == oracle_sums(t, bpc, bytes.substr(bpc, 70000 - bpc)));
+    ChunkBufferPtr inc = ChunkBuffer::allocate(n, bpc);   // stream.buffer.increment == bytes.per.checksum
+    for (int o = 0; o < n; o += 7777) inc->put(bytes.substr((size_t)o, 7777));
+    EXPECT(inc->position() == n);
+    ChunkBufferPtr incAll = inc->duplicate(0, n);
+    EXPECT(ck.computeChecksum(*incAll).getChecksums() == want);
+    try {
+      ChunkBufferPtr d = inc->duplicate(0, n);
+      Checksum(t, 8192).computeChecksum(*d);
+      EXPECT(!"mismatched increment accepted");
+    } catch (const UnsupportedOperationException& e) {
+      EXPECT(std::string(e.what()) == "Buffer size and increment mismatched: bufferSize = 8192 but increment = 16384");
+    }
+    // consumed buffers of a duplicate are handed out as they are: digests of the empty message lead the list
+    ChunkBufferPtr tailBuf = inc->duplicate(2 * bpc, n);
+    const std::vector<ByteString> tail = ck.computeChecksum(*tailBuf).getChecksums();
+    EXPECT(tail.size() == want.size());
+    for (size_t i = 2; i < want.size() && i < tail.size(); i++) EXPECT(tail[i] == want[i]);
+    std::string emptyDigest(oracle_digest_size((int)t), '\0');
+    if (t == ChecksumType::SHA256) oracle_sha256((const uint8_t*)"", 0, (uint8_t*)&emptyDigest[0]);
+    if (t == ChecksumType::MD5) oracle_md5((const uint8_t*)"", 0, (uint8_t*)&emptyDigest[0]);
+    EXPECT(tail.size() > 1 && tail[0] == emptyDigest && tail[1] == emptyDigest);
+    // one buffer per window (a ReadChunk V1 response): the reference's iteration visits 4 of these 7 elements
+    std::vector<ByteBufferPtr> parts;
+    std::vector<size_t> lengths;
+    for (int o = 0; o < n; o += bpc) {
+      parts.push_back(ByteBuffer::wrapReadOnly(bytes.data() + o, (size_t)std::min(bpc, n - o)));
+      lengths.push_back((size_t)parts.back()->remaining());
+    }
+    ChunkBufferPtr lst = ChunkBuffer::wrap(parts);
+    std::vector<ByteString> subset;
+    for (size_t i : referenceListWindows(lengths)) subset.push_back(want[i]);
+    EXPECT(ck.computeChecksum(*lst).getChecksums() == subset);
+    for (auto& b : parts) b->rewind();
+    ChunkBufferImplWithByteBufferList every(parts, false);
+    EXPECT(ck.computeChecksum(every).getChecksums() == want);
+  }
   std::printf(failures ? "%d FAILURES\n" : "host mirror: all passed\n", failures);
   ozcs_shutdown();
   return failures ? 1 : 0;

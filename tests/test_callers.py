@@ -288,3 +288,48 @@ def test_write_path_like_TestBlockOutputStreamCorrectness(conf):
 def native_digest_size(t):
     from hadoop_ozone_amd import native
     return native.DIGEST_SIZE[int(t)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("t", ["CRC32", "CRC32C", "SHA256", "MD5"])
+def test_computeChecksum_of_the_three_chunk_buffers(t):
+    # Checksum.computeChecksum(ChunkBuffer), Checksum.java:155-177, over each ChunkBuffer implementation: the
+    # windows are the ones iterate(bytesPerChecksum) cuts (ChunkBuffer.java:124), digests by the GPU library
+    from hadoop_ozone_amd import ByteBuffer, Checksum, ChunkBuffer
+    typ, otyp = ChecksumType[t], getattr(oracle, t)
+    n, bpc = 100000, 16384
+    data = oracle.splitmix64(97, n).tobytes()
+    want = [oracle.compute(otyp, bpc, data[o:o + bpc]) for o in range(0, n, bpc)]
+    ck = Checksum(typ, bpc)
+
+    one = ChunkBuffer.allocate(n).put(data)            # what BufferPool hands out without an increment
+    dup = one.duplicate(0, one.position())
+    assert ck.computeChecksum(dup).getChecksums() == want
+    assert dup.position() == dup.limit() == n          # "upon the iteration complete, position == limit"
+    assert ck.computeChecksum(ByteBuffer.wrap(data)).getChecksums() == want   # computeChecksum(ByteBuffer)
+    # a window range in the middle: position 16384, limit 70000
+    mid = one.duplicate(bpc, 70000)
+    assert ck.computeChecksum(mid).getChecksums() == [oracle.compute(otyp, bpc, data[o:min(o + bpc, 70000)])
+                                                      for o in range(bpc, 70000, bpc)]
+
+    inc = ChunkBuffer.allocate(n, bpc)                 # stream.buffer.increment == bytes.per.checksum
+    for o in range(0, n, 7777):                        # filled by writes of an odd size
+        inc.put(data[o:o + 7777])
+    assert inc.position() == n
+    assert ck.computeChecksum(inc.duplicate(0, n)).getChecksums() == want
+    with pytest.raises(Exception, match="Buffer size and increment mismatched: bufferSize = 8192 but increment = 16384"):
+        Checksum(typ, 8192).computeChecksum(inc.duplicate(0, n))
+    # consumed buffers of a duplicate are handed out as they are: digests of the empty message lead the list
+    # (IncrementalChunkBuffer.java:250-259 over :223-247)
+    tail = ck.computeChecksum(inc.duplicate(2 * bpc, n)).getChecksums()
+    empty = {"CRC32": lambda: oracle.crc32(b"").to_bytes(4, "big"), "CRC32C": lambda: oracle.crc32c(b"").to_bytes(4, "big"),
+             "SHA256": lambda: oracle.sha256(b""), "MD5": lambda: oracle.md5(b"")}[t]()
+    assert tail[2:] == want[2:] and tail[0] == tail[1] == empty
+
+    parts = [data[o:o + bpc] for o in range(0, n, bpc)]   # a ReadChunk V1 response: one buffer per window
+    lst = ChunkBuffer.wrap([ByteBuffer.wrap(p) for p in parts])
+    from hadoop_ozone_amd.checksum import reference_list_windows
+    assert ck.computeChecksum(lst).getChecksums() == [want[i] for i in reference_list_windows([len(p) for p in parts])]
+    from hadoop_ozone_amd.chunk_buffer import ChunkBufferImplWithByteBufferList
+    every = ChunkBufferImplWithByteBufferList([ByteBuffer.wrap(p) for p in parts], reference_list_quirk=False)
+    assert ck.computeChecksum(every).getChecksums() == want
