@@ -1,7 +1,8 @@
 /*
  * JNI shim between org.apache.hadoop.ozone.common.GpuChecksum and the C ABI (include/ozone_checksum.h).
- * The build image has no JDK (no jni.h), so no loadable shim has been built here; the file is kept
- * syntax- and signature-checked against a declaration stub (tests/jni_stub/jni.h, tests/test_jni_shim.py).
+ * The build image has no JDK (no jni.h), so no JVM-loadable shim has been built here; the file is kept
+ * syntax- and signature-checked against a declaration stub (tests/jni_stub/jni.h) and its functions are
+ * run on the GPU over a stand-in function table (tests/jni_stub/fake_jvm.c, tests/test_jni_shim.py).
  * Build where a JDK exists:
  *   gcc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -I../../include \
  *       ozcs_jni.c -L../csrc -lozcs -lpthread -o libozcs_jni.so

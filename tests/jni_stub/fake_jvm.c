@@ -1,0 +1,76 @@
+/*
+ * A stand-in for the JVM side of the JNI calls hadoop-ozone_amd/jni/ozcs_jni.c makes, for tests only: the shim is
+ * compiled against the declaration stub next to this file and driven through this function table from Python
+ * (ctypes), so that its own logic -- argument checks, the heap-array path through its pinned pipe, the malloc'd
+ * path, direct buffers, the pipe wrappers, the error mapping -- runs on the GPU through the C ABI.  A Java array
+ * or direct buffer is a small record here (kind, storage, length); region calls outside an array raise the
+ * pending-exception flag as ArrayIndexOutOfBoundsException would.  Nothing of this reaches a real JVM.
+ */
+#include <jni.h>
+#include <stdlib.h>
+#include <string.h>
+
+enum { kByteArray = 1, kIntArray = 2, kDirectBuffer = 3 };
+struct _jobject {
+  int kind;
+  void* ptr;
+  long len; /* elements for arrays, bytes of capacity for direct buffers */
+};
+
+static __thread int t_pending; /* an exception is pending on this thread */
+
+static jsize GetArrayLength(JNIEnv* env, jarray a) { (void)env; return (jsize)a->len; }
+static int region_ok(jarray a, int kind, jsize start, jsize len) {
+  if (a && a->kind == kind && start >= 0 && len >= 0 && (long)start + len <= a->len) return 1;
+  t_pending = 1;
+  return 0;
+}
+static void GetByteArrayRegion(JNIEnv* env, jbyteArray a, jsize start, jsize len, jbyte* buf) {
+  (void)env;
+  if (region_ok(a, kByteArray, start, len)) memcpy(buf, (jbyte*)a->ptr + start, (size_t)len);
+}
+static void SetByteArrayRegion(JNIEnv* env, jbyteArray a, jsize start, jsize len, const jbyte* buf) {
+  (void)env;
+  if (region_ok(a, kByteArray, start, len)) memcpy((jbyte*)a->ptr + start, buf, (size_t)len);
+}
+static void SetIntArrayRegion(JNIEnv* env, jintArray a, jsize start, jsize len, const jint* buf) {
+  (void)env;
+  if (region_ok(a, kIntArray, start, len)) memcpy((jint*)a->ptr + start, buf, (size_t)len * sizeof(jint));
+}
+static jboolean ExceptionCheck(JNIEnv* env) { (void)env; return t_pending ? JNI_TRUE : JNI_FALSE; }
+static jobject NewDirectByteBuffer(JNIEnv* env, void* address, jlong capacity) {
+  (void)env;
+  jobject o = (jobject)malloc(sizeof(struct _jobject));
+  if (!o) return NULL;
+  o->kind = kDirectBuffer;
+  o->ptr = address;
+  o->len = (long)capacity;
+  return o;
+}
+static void* GetDirectBufferAddress(JNIEnv* env, jobject b) { (void)env; return b && b->kind == kDirectBuffer ? b->ptr : NULL; }
+static jlong GetDirectBufferCapacity(JNIEnv* env, jobject b) { (void)env; return b && b->kind == kDirectBuffer ? b->len : -1; }
+
+static const struct JNINativeInterface_ g_table = {
+    GetArrayLength, GetByteArrayRegion, SetByteArrayRegion, SetIntArrayRegion,
+    ExceptionCheck, NewDirectByteBuffer, GetDirectBufferAddress, GetDirectBufferCapacity,
+};
+static JNIEnv g_env = &g_table;
+
+/* ---- what the Python side calls ---- */
+JNIEXPORT JNIEnv* fake_env(void) { return &g_env; }
+JNIEXPORT jobject fake_object(int kind, void* storage, long len) {
+  jobject o = (jobject)malloc(sizeof(struct _jobject));
+  if (!o) return NULL;
+  o->kind = kind;
+  o->ptr = storage;
+  o->len = len;
+  return o;
+}
+JNIEXPORT void fake_release(jobject o) { free(o); }
+JNIEXPORT void* fake_storage(jobject o) { return o ? o->ptr : NULL; }
+JNIEXPORT long fake_length(jobject o) { return o ? o->len : -1; }
+JNIEXPORT int fake_exception_pending(int clear) {
+  const int p = t_pending;
+  if (clear) t_pending = 0;
+  return p;
+}

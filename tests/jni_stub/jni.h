@@ -1,8 +1,9 @@
 /*
- * Declaration stub of the few JNI names hadoop-ozone_amd/jni/ozcs_jni.c uses, written by hand for ONE purpose:
- * `gcc -fsyntax-only` of the shim in an image that has no JDK, so that drift between the shim, the C ABI header
- * and GpuChecksum.java is caught by a test.  It is not the JDK's jni.h, declares nothing else, and must never be
- * used to build a shim that is loaded into a JVM (the function table's layout here is not the real one).
+ * Declaration stub of the few JNI names hadoop-ozone_amd/jni/ozcs_jni.c uses, written by hand for tests in an image
+ * that has no JDK: `gcc -fsyntax-only` of the shim, so that drift between the shim, the C ABI header and
+ * GpuChecksum.java is caught, and a test build of the shim that is driven through the stand-in function table of
+ * fake_jvm.c.  It is not the JDK's jni.h, declares nothing else, and must never be used to build a shim that is
+ * loaded into a JVM (the function table's layout here is not the real one).
  */
 #ifndef OZCS_TEST_JNI_STUB_H
 #define OZCS_TEST_JNI_STUB_H

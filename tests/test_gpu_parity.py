@@ -412,6 +412,24 @@ def test_reference_TestChecksum(gpu):
         Checksum.verifyChecksum(whole, ChecksumData(ChecksumType.CRC32, 20, cd.getChecksums()[:2]), 0)
 
 
+@pytest.mark.parametrize("t", [oracle.CRC32, oracle.CRC32C])
+def test_reference_TestChecksumImplsComputeSameValues(gpu, t):
+    # TestChecksumImplsComputeSameValues.java:38-101: 64 MiB of random bytes, six window sizes, every engine must
+    # give the same value for every window.  Here the engines are the GPU kernels (host-pointer call and
+    # device-resident call), the oracle's slice-by-8 restatement and its carry-less-multiply engine.
+    torch, native, L = gpu
+    n = 64 << 20
+    host = np.random.default_rng(64 + t).integers(0, 256, n, dtype=np.uint8)
+    dtensor = torch.from_numpy(host).cuda()
+    for bpc in (512, 1024, 2048, 4096, 32768, 1048576):
+        want = oracle.compute(t, bpc, host)
+        assert len(want) == 4 * (n // bpc)
+        assert native.compute(t, bpc, host) == want
+        assert dev_compute(gpu, t, bpc, dtensor, n, 1, n) == want
+        if oracle.has_clmul():
+            assert oracle.compute_clmul(t, bpc, host) == want
+
+
 # ------------------------------------------------------------------ asynchronous pinned pipeline
 
 def test_pipe_mixed_types_against_oracle(gpu):

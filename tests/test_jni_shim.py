@@ -43,3 +43,153 @@ def test_every_java_native_method_has_a_matching_definition():
         assert ctypes_[:2] == ["JNIEnv*", "jclass"], name
         assert ctypes_[2:] == jtypes, (name, ctypes_[2:], jtypes)
         assert cret == JAVA_TO_JNI[ret], name
+
+
+# ------------------------------------------------------------------ the shim, executed: stand-in JNI function table
+
+import ctypes  # noqa: E402
+
+import numpy as np  # noqa: E402
+import pytest  # noqa: E402
+
+FAKE = os.path.join(ROOT, "tests", "jni_stub", "libozcs_jni_fake.so")
+K_BYTES, K_INTS, K_DIRECT = 1, 2, 3
+PFX = "Java_org_apache_hadoop_ozone_common_GpuChecksum_"
+
+
+class FakeJvm:
+    """ctypes view of the shim built against tests/jni_stub (jni.h + fake_jvm.c): Java arrays and direct buffers
+    are numpy arrays wrapped in the stand-in's object records."""
+
+    def __init__(self):
+        import torch  # noqa: F401  (first, so that the shim's libozcs shares torch's HIP runtime)
+        assert os.path.exists(FAKE), "run __graft_entry__.build() first"
+        self.lib = L = ctypes.CDLL(FAKE)
+        L.fake_env.restype = ctypes.c_void_p
+        L.fake_object.restype = ctypes.c_void_p
+        L.fake_object.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_long]
+        L.fake_release.argtypes = [ctypes.c_void_p]
+        L.fake_storage.restype = ctypes.c_void_p
+        L.fake_storage.argtypes = [ctypes.c_void_p]
+        L.fake_length.restype = ctypes.c_long
+        L.fake_length.argtypes = [ctypes.c_void_p]
+        self.env = L.fake_env()
+        self.keep = []
+        V, I, J, B = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint8
+        sig = {"nativeAvailable": (B, []),
+               "calculateChunkedSumsByteArray": (J, [I, I, V, I, V, I, I]),
+               "calculateChunkedSumsDirect": (J, [I, I, V, I, I, V, I, I]),
+               "verifyChunkedSumsByteArray": (J, [I, I, V, I, I, I, V, I, I]),
+               "pipeCreate": (J, [I, I, J]), "pipeDestroy": (None, [J]), "pipeAcquire": (V, [J, V]),
+               "pipeSubmit": (I, [J, I, I, I, J, V]), "pipeWait": (J, [J, I]),
+               "pipeNextCompleted": (J, [J, B, V]), "pipeTicketSlot": (I, [I])}
+        for name, (ret, args) in sig.items():
+            f = getattr(L, PFX + name)
+            f.restype = ret
+            f.argtypes = [V, V] + args
+            setattr(self, name, (lambda f: lambda *a: f(self.env, None, *a))(f))
+
+    def obj(self, kind, arr):
+        self.keep.append(arr)
+        return self.lib.fake_object(kind, arr.ctypes.data, arr.size)
+
+    def pending(self, clear=True):
+        return self.lib.fake_exception_pending(1 if clear else 0)
+
+
+@pytest.fixture(scope="module")
+def jvm():
+    return FakeJvm()
+
+
+@pytest.mark.gpu
+def test_shim_heap_arrays_through_its_pinned_pipe_and_beyond_a_slot(jvm):
+    import oracle
+    assert jvm.nativeAvailable() == 1
+    for t, ds in ((oracle.CRC32, 4), (oracle.CRC32C, 4), (oracle.SHA256, 32), (oracle.MD5, 16)):
+        for n, bpc, off in ((4 << 20, 1 << 20, 0), (100000, 16384, 7), (12 << 20, 1 << 20, 3), (1, 512, 0)):
+            if ds > 4 and n > (4 << 20):
+                continue
+            heap = oracle.splitmix64(n + t, n + off + 5)          # the Java array, with bytes around the range
+            want = oracle.compute(t, bpc, heap[off:off + n])
+            sums = np.full(len(want) + 9, 0xEE, dtype=np.uint8)
+            got = jvm.calculateChunkedSumsByteArray(bpc, t, jvm.obj(K_BYTES, sums), 4, jvm.obj(K_BYTES, heap), off, n)
+            assert got == len(want) // ds and not jvm.pending()
+            assert bytes(sums[4:4 + len(want)]) == want
+            assert bytes(sums[:4]) == b"\xee" * 4 and bytes(sums[4 + len(want):]) == b"\xee" * 5
+    # NONE: no digests; bad arguments: the library's EINVAL (-1), nothing written, no exception left pending
+    heap = oracle.splitmix64(5, 100)
+    sums = np.zeros(16, dtype=np.uint8)
+    assert jvm.calculateChunkedSumsByteArray(10, 1, jvm.obj(K_BYTES, sums), 0, jvm.obj(K_BYTES, heap), 0, 100) == 0
+    assert jvm.calculateChunkedSumsByteArray(10, oracle.CRC32, jvm.obj(K_BYTES, sums), 0, jvm.obj(K_BYTES, heap), 0, 100) == -1  # 40 B of sums needed
+    assert jvm.calculateChunkedSumsByteArray(10, oracle.CRC32, jvm.obj(K_BYTES, sums), 0, jvm.obj(K_BYTES, heap), 95, 10) == -1
+    assert jvm.calculateChunkedSumsByteArray(0, oracle.CRC32, jvm.obj(K_BYTES, sums), 0, jvm.obj(K_BYTES, heap), 0, 10) == -1
+    assert jvm.calculateChunkedSumsByteArray(10, 9, jvm.obj(K_BYTES, sums), 0, jvm.obj(K_BYTES, heap), 0, 10) == -1
+    assert not jvm.pending() and not sums.any()
+
+
+@pytest.mark.gpu
+def test_shim_direct_buffers_and_verify(jvm):
+    import oracle
+    n, bpc = 300000, 16384
+    data = oracle.splitmix64(77, n + 64)
+    want = oracle.compute(oracle.CRC32C, bpc, data[64:64 + n])
+    sums = np.zeros(len(want) + 8, dtype=np.uint8)
+    got = jvm.calculateChunkedSumsDirect(bpc, oracle.CRC32C, jvm.obj(K_DIRECT, sums), 8, sums.size,
+                                         jvm.obj(K_DIRECT, data), 64, 64 + n)   # position / limit come from Java
+    assert got == len(want) // 4 and bytes(sums[8:]) == want
+    assert jvm.calculateChunkedSumsDirect(bpc, oracle.CRC32C, jvm.obj(K_DIRECT, sums), 8, sums.size,
+                                          jvm.obj(K_BYTES, data), 64, 64 + n) == -1     # a heap buffer has no address
+    assert jvm.calculateChunkedSumsDirect(bpc, oracle.CRC32C, jvm.obj(K_DIRECT, sums), 8, sums.size,
+                                          jvm.obj(K_DIRECT, data), 64, n + 65) == -1    # limit beyond the capacity
+    # verify: -1 = all windows match, k >= 0 = first failing window relative to the computed list, < -1 = error
+    stored = np.frombuffer(want, dtype=np.uint8).copy()
+    heap = data.copy()
+    args = lambda d, start=0, nsums=len(want) // 4: (bpc, oracle.CRC32C, jvm.obj(K_BYTES, stored), 0, nsums, start,
+                                                      jvm.obj(K_BYTES, d), 64, n)
+    assert jvm.verifyChunkedSumsByteArray(*args(heap)) == -1
+    heap[64 + 5 * bpc + 3] ^= 1
+    assert jvm.verifyChunkedSumsByteArray(*args(heap)) == 5
+    assert jvm.verifyChunkedSumsByteArray(*args(data, nsums=3)) < -1     # fewer stored sums than windows (OZCS_ERANGE)
+    # startIndex: windows 2.. of the chunk against the stored list from index 2
+    assert jvm.verifyChunkedSumsByteArray(bpc, oracle.CRC32C, jvm.obj(K_BYTES, stored), 0, len(want) // 4, 2,
+                                          jvm.obj(K_BYTES, data), 64 + 2 * bpc, n - 2 * bpc) == -1
+
+
+@pytest.mark.gpu
+def test_shim_pipe_wrappers(jvm):
+    import oracle
+    pipe = jvm.pipeCreate(0, 4, 1 << 20)
+    assert pipe != 0
+    try:
+        chunks, tickets, outs = [], [], []
+        for i in range(4):
+            tk = np.zeros(1, dtype=np.int32)
+            buf = jvm.pipeAcquire(pipe, jvm.obj(K_INTS, tk))       # a direct ByteBuffer over the pinned slot
+            assert buf and jvm.lib.fake_length(buf) == 1 << 20
+            n = (1 << 20) - 1000 * i
+            d = oracle.splitmix64(900 + i, n)
+            ctypes.memmove(jvm.lib.fake_storage(buf), d.ctypes.data, n)
+            out = np.zeros(64 * 16, dtype=np.uint8)
+            t = oracle.MD5 if i % 2 else oracle.CRC32
+            assert jvm.pipeSubmit(pipe, int(tk[0]), t, 65536, n, jvm.obj(K_DIRECT, out)) == 0
+            assert jvm.pipeTicketSlot(int(tk[0])) == i
+            chunks.append((t, d)); tickets.append(int(tk[0])); outs.append(out)
+        tk = np.zeros(1, dtype=np.int32)
+        assert jvm.pipeAcquire(pipe, jvm.obj(K_INTS, tk)) is None   # every slot held: null, as the Java side expects
+        assert jvm.pipeWait(pipe, tickets[0]) == 16
+        seen = {tickets[0]}
+        while True:
+            ts = np.zeros(2, dtype=np.int32)
+            n = jvm.pipeNextCompleted(pipe, 1, jvm.obj(K_INTS, ts))
+            if n < 0:
+                assert n == -6                                       # OZCS_EEMPTY: nothing outstanding any more
+                break
+            assert ts[1] == 0 and n == 16
+            seen.add(int(ts[0]))
+        assert seen == set(tickets)
+        for (t, d), out in zip(chunks, outs):
+            want = oracle.compute(t, 65536, d)
+            assert bytes(out[:len(want)]) == want
+    finally:
+        jvm.pipeDestroy(pipe)
