@@ -29,7 +29,8 @@
 //   crc_windows_kernel  G wavefronts per window (1..16), for windows above 256 KiB or scarce windows;
 //   crc_subwave_kernel  4..32 lanes per window, any alignment and ragged last windows;
 //   crc_flat_kernel     the same for the gapless layout (full, aligned windows back to back), where the
-//                       per-window geometry disappears.
+//                       per-window geometry disappears; optionally with the wavefronts entering their windows
+//                       at four different offsets.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -82,6 +83,20 @@ __device__ __forceinline__ uint32_t nib_apply(const char* lds, int op, uint32_t 
   for (int k = 0; k < 4; k++) {
     t[2 * k] = lds_u32(lds, __builtin_amdgcn_perm(m0, kNibOff, 0x0c020104u + k) + (off + (2 * k) * 64u));
     t[2 * k + 1] = lds_u32(lds, __builtin_amdgcn_perm(m1, kNibOff, 0x0c020104u + k) + (off + (2 * k + 1) * 64u));
+  }
+  return xor3(xor3(t[0], t[1], t[2]), xor3(t[3], t[4], t[5]), t[6] ^ t[7]);
+}
+
+// The same with the operator chosen at run time: `area` = kNibOff + op * kNibOpBytes (a multiple of 256, uniform
+// over the wavefront) takes the table area's place in the address.
+__device__ __forceinline__ uint32_t nib_apply_at(const char* lds, uint32_t area, uint32_t x) {
+  const uint32_t m0 = (x << 2) & 0x3c3c3c3cu;
+  const uint32_t m1 = (x >> 2) & 0x3c3c3c3cu;
+  uint32_t t[8];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    t[2 * k] = lds_u32(lds, __builtin_amdgcn_perm(m0, area, 0x0c020104u + k) + (2 * k) * 64u);
+    t[2 * k + 1] = lds_u32(lds, __builtin_amdgcn_perm(m1, area, 0x0c020104u + k) + (2 * k + 1) * 64u);
   }
   return xor3(xor3(t[0], t[1], t[2]), xor3(t[3], t[4], t[5]), t[6] ^ t[7]);
 }
@@ -611,10 +626,20 @@ __global__ __launch_bounds__(kThreads) void crc_desc_kernel(const WindowDesc* de
 // 4.1 TB/s at 512-byte windows, 5.3 with the two halves of a line requested by adjacent instructions
 // (UNR = 2), against 5.8 for 8 lanes (profiles/r01_crc_flat_sweep.log).  UNR = 2 is used where it measured
 // faster: windows of 256 bytes and less.
-template <int LPW, int MODE, int UNR>
+//
+// Phases (PH = 4).  Left alone, every wavefront of the chip walks through its windows from offset 0, so at any
+// moment tens of thousands of reads go to addresses that agree in the bits below the window size; a bare read in
+// that pattern runs at 6.2-6.9 TB/s for windows of 4 to 32 KiB, and at 7.0-7.2 when the wavefronts of a workgroup
+// start 0, 1/4, 1/2 and 3/4 of the way into their windows and wrap round (tools/hbm_read_bench.hip, "flat").  A
+// CRC does not care where its window is entered: with window = head | tail, the wavefront sums the tail first,
+// parks those accumulators at the wrap, sums the head on fresh ones (the initial register belongs to the head),
+// and at the end advances the head's accumulators through the tail's length -- 3/4, 1/2 or 1/4 of a power-of-two
+// window: one or two of the power-of-two nibble operators -- and XORs the tail's in.  The fold is unchanged.
+template <int LPW, int MODE, int UNR, int PH>
 __global__ __launch_bounds__(kThreads) void crc_flat_kernel(const CrcLaunch p) {
   __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
   constexpr uint32_t kStripe = 16u * LPW;
+  constexpr uint32_t kGroup = UNR * kStripe;  // bytes of a window one load group covers
   constexpr int kWinPerRow = 64 / LPW;
   constexpr int kWinPerWave = 2 * kWinPerRow;
   constexpr int kLevels = LPW == 4 ? 2 : LPW == 8 ? 3 : LPW == 16 ? 4 : 5;
@@ -630,56 +655,93 @@ __global__ __launch_bounds__(kThreads) void crc_flat_kernel(const CrcLaunch p) {
   const uint32_t lb23 = lb01 + 65536u;
   const int sl = lane & (LPW - 1);
   const int grp = lane / LPW;
-  const uint32_t nst = p.bpc / kStripe;  // a multiple of UNR
   const uint32_t init = sl == 0 ? 0xFFFFFFFFu : 0u;  // the window's first four bytes are lane 0's first dword
   const uintptr_t base = reinterpret_cast<uintptr_t>(p.data) + 16u * sl;
   const uint64_t last = p.n_windows - 1;
+  // PH > 1: this wavefront starts `phase` bytes into each of its windows and wraps round (bpc is then a power of
+  // two and a multiple of PH load groups); the part behind the phase is the window's tail, read first
+  const uint32_t phase = PH > 1 ? (uint32_t)(wave & (PH - 1)) * (p.bpc / PH) : 0u;
+  const uint32_t init0 = phase == 0 ? init : 0u;
 
   for (uint64_t w0 = ((uint64_t)blockIdx.x * kWaves + wave) * kWinPerWave; w0 < p.n_windows;
        w0 += (uint64_t)gridDim.x * kWaves * kWinPerWave) {
     const uint64_t ga = w0 + grp, gb = w0 + kWinPerRow + grp;
-    uintptr_t ua = base + (ga < last ? ga : last) * p.bpc, ub = base + (gb < last ? gb : last) * p.bpc;
+    const uintptr_t wa = base + (ga < last ? ga : last) * p.bpc, wb = base + (gb < last ? gb : last) * p.bpc;
     uint4 ca[UNR], cb[UNR], na[UNR], nb[UNR];
+    uint32_t off = phase;  // offset of the load group in hand
 #pragma unroll
     for (int k = 0; k < UNR; k++) {
-      ca[k] = ld16(ua + k * kStripe);
-      cb[k] = ld16(ub + k * kStripe);
+      ca[k] = ld16(wa + off + k * kStripe);
+      cb[k] = ld16(wb + off + k * kStripe);
     }
-    if (nst > UNR) {
-      ua += UNR * kStripe;
-      ub += UNR * kStripe;
+    uint32_t noff = off + kGroup;  // offset of the load group in flight
+    if (PH > 1 && noff == p.bpc) noff = 0;
+    if (p.bpc > kGroup) {
 #pragma unroll
       for (int k = 0; k < UNR; k++) {
-        na[k] = ld16(ua + k * kStripe);
-        nb[k] = ld16(ub + k * kStripe);
+        na[k] = ld16(wa + noff + k * kStripe);
+        nb[k] = ld16(wb + noff + k * kStripe);
       }
     }
-    Acc4 a = {ca[0].x ^ init, ca[0].y, ca[0].z, ca[0].w}, b = {cb[0].x ^ init, cb[0].y, cb[0].z, cb[0].w};
+    Acc4 a = {ca[0].x ^ init0, ca[0].y, ca[0].z, ca[0].w}, b = {cb[0].x ^ init0, cb[0].y, cb[0].z, cb[0].w};
+    Acc4 ta = {0, 0, 0, 0}, tb = {0, 0, 0, 0};  // PH > 1: the accumulators of the tail, parked at the wrap
 #pragma unroll
     for (int k = 1; k < UNR; k++) {
       absorb(lds, lb01, lb23, a, ca[k]);
       absorb(lds, lb01, lb23, b, cb[k]);
     }
-    for (uint32_t j = UNR; j < nst; j += UNR) {
+    for (uint32_t done = kGroup; done < p.bpc; done += kGroup) {
+      off = noff;
 #pragma unroll
       for (int k = 0; k < UNR; k++) {
         ca[k] = na[k];
         cb[k] = nb[k];
       }
-      if (j + UNR < nst) {
-        ua += UNR * kStripe;
-        ub += UNR * kStripe;
+      if (done + kGroup < p.bpc) {
+        noff = off + kGroup;
+        if (PH > 1 && noff == p.bpc) noff = 0;
 #pragma unroll
         for (int k = 0; k < UNR; k++) {
-          na[k] = ld16(ua + k * kStripe);
-          nb[k] = ld16(ub + k * kStripe);
+          na[k] = ld16(wa + noff + k * kStripe);
+          nb[k] = ld16(wb + noff + k * kStripe);
         }
       }
+      if (PH > 1 && off == 0) {  // wrapped round: the window's head starts here, on accumulators of its own
+        ta = a;
+        tb = b;
+        a = {ca[0].x ^ init, ca[0].y, ca[0].z, ca[0].w};
+        b = {cb[0].x ^ init, cb[0].y, cb[0].z, cb[0].w};
 #pragma unroll
-      for (int k = 0; k < UNR; k++) {
-        absorb(lds, lb01, lb23, a, ca[k]);
-        absorb(lds, lb01, lb23, b, cb[k]);
+        for (int k = 1; k < UNR; k++) {
+          absorb(lds, lb01, lb23, a, ca[k]);
+          absorb(lds, lb01, lb23, b, cb[k]);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < UNR; k++) {
+          absorb(lds, lb01, lb23, a, ca[k]);
+          absorb(lds, lb01, lb23, b, cb[k]);
+        }
       }
+    }
+    if (PH > 1 && phase != 0) {
+      // window = head | tail: the head's accumulators advance through the tail's bpc - phase bytes (one or two
+      // power-of-two operators: PH = 4 gives tails of 3/4, 1/2 and 1/4 of a window) and meet the tail's
+      const uint32_t half = kNibOff + (uint32_t)(__builtin_ctz(p.bpc) - 2) * kNibOpBytes;  // operator of bpc / 2 bytes
+      const uint32_t quarter = half - kNibOpBytes;
+      const uint32_t tail = p.bpc - phase;
+      uint32_t* va[8] = {&a.a0, &a.a1, &a.a2, &a.a3, &b.a0, &b.a1, &b.a2, &b.a3};
+      const uint32_t vt[8] = {ta.a0, ta.a1, ta.a2, ta.a3, tb.a0, tb.a1, tb.a2, tb.a3};
+      if (tail & (p.bpc >> 1)) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) *va[k] = nib_apply_at(lds, half, *va[k]);
+      }
+      if (tail & (p.bpc >> 2)) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) *va[k] = nib_apply_at(lds, quarter, *va[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k++) *va[k] ^= vt[k];
     }
     const uint32_t z4base = kZ4Off + 4u * (uint32_t)(sl & 3);
     uint32_t x = slot_fold_chain(lds, z4base, a), y = slot_fold_chain(lds, z4base, b);
@@ -711,18 +773,21 @@ __global__ __launch_bounds__(kThreads) void crc_flat_kernel(const CrcLaunch p) {
   }
 }
 
-// (lanes per window, stripes per load group) pairs that are built
+// (lanes per window, stripes per load group, phases) triples that are built
 template <int MODE>
-hipError_t launch_flat(const CrcLaunch& p, int lpw, int unr, int blocks, hipStream_t stream) {
-  switch (lpw * 8 + unr) {
-    case 4 * 8 + 1: crc_flat_kernel<4, MODE, 1><<<blocks, kThreads, 0, stream>>>(p); break;
-    case 4 * 8 + 2: crc_flat_kernel<4, MODE, 2><<<blocks, kThreads, 0, stream>>>(p); break;
-    case 8 * 8 + 1: crc_flat_kernel<8, MODE, 1><<<blocks, kThreads, 0, stream>>>(p); break;
-    case 8 * 8 + 2: crc_flat_kernel<8, MODE, 2><<<blocks, kThreads, 0, stream>>>(p); break;
-    case 16 * 8 + 1: crc_flat_kernel<16, MODE, 1><<<blocks, kThreads, 0, stream>>>(p); break;
-    case 16 * 8 + 2: crc_flat_kernel<16, MODE, 2><<<blocks, kThreads, 0, stream>>>(p); break;
-    case 32 * 8 + 1: crc_flat_kernel<32, MODE, 1><<<blocks, kThreads, 0, stream>>>(p); break;
-    case 32 * 8 + 2: crc_flat_kernel<32, MODE, 2><<<blocks, kThreads, 0, stream>>>(p); break;
+hipError_t launch_flat(const CrcLaunch& p, int lpw, int unr, int phases, int blocks, hipStream_t stream) {
+  switch (phases * 1000 + lpw * 8 + unr) {
+    case 1000 + 4 * 8 + 1: crc_flat_kernel<4, MODE, 1, 1><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 1000 + 4 * 8 + 2: crc_flat_kernel<4, MODE, 2, 1><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 1000 + 8 * 8 + 1: crc_flat_kernel<8, MODE, 1, 1><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 1000 + 8 * 8 + 2: crc_flat_kernel<8, MODE, 2, 1><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 1000 + 16 * 8 + 1: crc_flat_kernel<16, MODE, 1, 1><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 1000 + 16 * 8 + 2: crc_flat_kernel<16, MODE, 2, 1><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 1000 + 32 * 8 + 1: crc_flat_kernel<32, MODE, 1, 1><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 1000 + 32 * 8 + 2: crc_flat_kernel<32, MODE, 2, 1><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 4000 + 8 * 8 + 1: crc_flat_kernel<8, MODE, 1, 4><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 4000 + 16 * 8 + 1: crc_flat_kernel<16, MODE, 1, 4><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 4000 + 32 * 8 + 1: crc_flat_kernel<32, MODE, 1, 4><<<blocks, kThreads, 0, stream>>>(p); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -764,6 +829,7 @@ const int g_force_lpw = env_int("OZCS_CRC_LPW");  // 4|8|16|32 lanes per window,
 const int g_no_aligned = env_int("OZCS_CRC_NO_ALIGNED");  // 1 = always take the any-alignment code path
 const int g_no_flat = env_int("OZCS_CRC_NO_FLAT");        // 1 = never take the gapless-full-windows kernel
 const int g_force_flat = env_int("OZCS_CRC_FLAT");        // lanes * 8 + stripes per load group, e.g. 34 = 4 lanes, 2 stripes
+const int g_force_phases = env_int("OZCS_CRC_PHASES");    // 1 = no wavefront starts inside its windows, 4 = four phases
 
 }  // namespace
 
@@ -842,16 +908,27 @@ hipError_t crc_launch(const CrcLaunch& launch, int mode, int group, int num_cus,
     if (gapless) {
       int fl = lpw, fu = (p.bpc <= 256 && p.bpc % (32u * lpw) == 0) ? 2 : 1;
       if (fl == 16 && p.bpc == 8192) fu = 2;  // measured: 6.82 against 6.73 TB/s with one stripe per load group
+      int fp = 1;
       if (g_force_flat > 0) {
         fl = g_force_flat / 8;
         fu = g_force_flat % 8;
       }
+      // Measured on MI355X (16 GiB batches, profiles/r02_crc_phases_sweep.log): four phases win where the windows
+      // of the chip's wavefronts would otherwise all be read at the same offset at the same time and that offset's
+      // address bits matter -- 6.94 against 6.84 TB/s at 16 KiB windows (8 lanes), 6.91 against 6.82 at 32 KiB
+      // (32 lanes); at 4 and 8 KiB the merge of head and tail costs what the reads gain, at 64 KiB nothing is gained.
+      if ((fl == 8 && p.bpc == 16384) || (fl == 32 && p.bpc == 32768)) fp = fu == 1 ? 4 : 1;
+      if (g_force_phases == 4) fp = 4;
+      if (g_force_phases == 1) fp = 1;
+      // four phases need the operators of bpc / 2 and bpc / 4 bytes (nibble tables reach 16 KiB) and whole load
+      // groups per quarter window
+      if (fp == 4 && ((p.bpc & (p.bpc - 1)) != 0 || p.bpc > 32768 || p.bpc < 64u * fl * fu)) fp = 1;
       if (p.bpc % (16u * fl * fu) == 0) {
         const uint64_t per = (uint64_t)kWaves * 2 * (64 / fl);
         uint64_t fb = (p.n_windows + per - 1) / per;
         if (fb > (uint64_t)num_cus) fb = num_cus;
-        const hipError_t e = mode == kModeCompute ? launch_flat<kModeCompute>(p, fl, fu, (int)fb, stream)
-                                                  : launch_flat<kModeVerify>(p, fl, fu, (int)fb, stream);
+        const hipError_t e = mode == kModeCompute ? launch_flat<kModeCompute>(p, fl, fu, fp, (int)fb, stream)
+                                                  : launch_flat<kModeVerify>(p, fl, fu, fp, (int)fb, stream);
         if (e != hipErrorInvalidValue) return e;
         (void)hipGetLastError();  // that (lanes, group) pair is not built: use the general kernel
       }

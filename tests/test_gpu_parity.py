@@ -535,6 +535,21 @@ def test_forced_kernel_variants_random_shapes(gpu, env):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("lanes", ["8", "16", "32"])
+def test_crc_wavefronts_starting_inside_their_windows(gpu, lanes):
+    # the gapless-layout kernel with four phases (wavefronts start 0, 1/4, 1/2, 3/4 into their windows and wrap
+    # round; head and tail are merged with the operators of bpc/2 and bpc/4 bytes): every power-of-two window size
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    e = dict(os.environ)
+    e.update({"OZCS_CRC_LPW": lanes, "OZCS_CRC_PHASES": "4"})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "variant_check.py"), "13", "pow2"], env=e,
+                       capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("split", ["0", "1"])
 def test_sha256_one_and_two_wavefront_forms(gpu, split):
     # the launcher picks the form by window count; both must be right on any shape (MD5 rides along)

@@ -14,6 +14,7 @@ from hadoop_ozone_amd import native
 def main():
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     digests = len(sys.argv) > 2 and sys.argv[2] == "digests"
+    pow2 = len(sys.argv) > 2 and sys.argv[2] == "pow2"   # gapless batches of power-of-two windows only
     rng = np.random.default_rng(seed)
     L = native.lib()
     native.check(L.ozcs_init(0))
@@ -35,6 +36,12 @@ def main():
                 bpc = bpc // 512 * 512
                 chunk_len = max(1, chunk_len // bpc) * bpc
                 stride = chunk_len
+        if pow2:
+            bpc = int(rng.choice([512, 2048, 4096, 8192, 16384, 32768, 65536]))
+            n_chunks = int(rng.integers(1, 4))
+            chunk_len = int(rng.integers(1, max(2, (3 << 20) // bpc))) * bpc
+            stride = chunk_len
+            off = 0
         t = oracle.CRC32 if case % 2 else oracle.CRC32C
         if digests:
             t = oracle.SHA256 if case % 4 else oracle.MD5

@@ -107,7 +107,10 @@ __global__ __launch_bounds__(1024) void read_crc_pattern(const uint8_t* p, uint6
 // with LDS != 0 the workgroup also holds 154 KiB of LDS like the CRC kernels (one workgroup per CU)
 // SPREAD (odd): logical window g is physical window (g * SPREAD) mod nwin, nwin a power of two -- the windows one
 // wavefront reads together are then SPREAD windows apart instead of adjacent
-template <int LPW, int LDS, int SPREAD = 1>
+// PHASE: every wavefront starts its windows at an offset of its own and wraps round (1: by wavefront number, 2: by
+// wavefront and workgroup number), so that the wavefronts of the chip do not all stand at the same offset inside
+// their windows at the same time
+template <int LPW, int LDS, int SPREAD = 1, int PHASE = 0>
 __global__ __launch_bounds__(1024) void read_flat_pattern(const uint8_t* p, uint64_t nwin, uint32_t win, uint32_t* out) {
   __shared__ char lds[LDS ? 157696 : 16];
   if (LDS && threadIdx.x == 0) lds[win & 15] = 1;
@@ -115,13 +118,25 @@ __global__ __launch_bounds__(1024) void read_flat_pattern(const uint8_t* p, uint
   constexpr int kPerRow = 64 / LPW;
   constexpr uint32_t kStripe = 16u * LPW;
   const int sl = lane & (LPW - 1), grp = lane / LPW;
+  const uint32_t nst = win / kStripe;
+  const uint32_t slot = PHASE == 2 ? (uint32_t)(wave * 16 + (blockIdx.x & 15)) : (uint32_t)wave * 16;
+  uint32_t ph = PHASE ? (uint32_t)(((uint64_t)slot * nst) >> 8) * kStripe : 0;
+  if (PHASE >= 4) ph = (uint32_t)(((uint64_t)(wave % PHASE) * nst) / PHASE) * kStripe;  // PHASE uniform phases
+  if (PHASE == 3) {  // the tail behind the phase is a power of two: win, win/2, win/4, ... (at least one stripe)
+    uint32_t tail = win >> (wave & 7);
+    if (tail < kStripe) tail = kStripe;
+    ph = win - tail;
+  }
   u32x4 acc = {0, 0, 0, 0};
   for (uint64_t w0 = ((uint64_t)blockIdx.x * 16 + wave) * 2 * kPerRow; w0 < nwin; w0 += (uint64_t)gridDim.x * 16 * 2 * kPerRow) {
     const uint64_t ga = w0 + grp, gb = w0 + kPerRow + grp;
     const uint8_t* qa = p + (((ga < nwin ? ga : nwin - 1) * SPREAD) & (nwin - 1)) * win + 16 * sl;
     const uint8_t* qb = p + (((gb < nwin ? gb : nwin - 1) * SPREAD) & (nwin - 1)) * win + 16 * sl;
-    u32x4 a = __builtin_nontemporal_load((gptr)qa), b = __builtin_nontemporal_load((gptr)qb);
-    for (uint32_t o = kStripe; o < win; o += kStripe) {
+    u32x4 a = __builtin_nontemporal_load((gptr)(qa + ph)), b = __builtin_nontemporal_load((gptr)(qb + ph));
+    uint32_t o = ph;
+    for (uint32_t k = 1; k < nst; k++) {
+      o += kStripe;
+      if (o >= win) o -= win;
       const u32x4 na = __builtin_nontemporal_load((gptr)(qa + o)), nb = __builtin_nontemporal_load((gptr)(qb + o));
       acc ^= a ^ b;
       a = na;
@@ -212,7 +227,7 @@ int main(int argc, char** argv) {
   const u32x4* p = (const u32x4*)d;
   printf("buffer %llu GiB\n", (unsigned long long)(bytes >> 30));
   if (argc > 2 && !strcmp(argv[2], "flat")) {   // bare reads in the small-window kernels' pattern, window size x lanes per window
-    for (uint32_t w : {512u, 4096u, 8192u, 16384u, 32768u, 65536u}) {
+    for (uint32_t w : {512u, 2048u, 4096u, 8192u, 16384u, 32768u, 65536u, 131072u}) {
       char name[96];
       const uint64_t nw = bytes / w;
       snprintf(name, sizeof name, "flat pattern %6u B windows,  8 lanes, LDS held", w);
@@ -223,6 +238,28 @@ int main(int argc, char** argv) {
       timeit(name, bytes, [&] { read_flat_pattern<32, 1><<<256, 1024>>>(d, nw, w, out); });
       snprintf(name, sizeof name, "flat pattern %6u B windows,  8 lanes, 2 workgroups per CU", w);
       timeit(name, bytes, [&] { read_flat_pattern<8, 0><<<512, 1024>>>(d, nw, w, out); });
+      snprintf(name, sizeof name, "flat pattern %6u B windows,  8 lanes, phase by wavefront", w);
+      timeit(name, bytes, [&] { read_flat_pattern<8, 1, 1, 1><<<256, 1024>>>(d, nw, w, out); });
+      snprintf(name, sizeof name, "flat pattern %6u B windows,  8 lanes, phase by wavefront and workgroup", w);
+      timeit(name, bytes, [&] { read_flat_pattern<8, 1, 1, 2><<<256, 1024>>>(d, nw, w, out); });
+      snprintf(name, sizeof name, "flat pattern %6u B windows, 16 lanes, phase by wavefront", w);
+      timeit(name, bytes, [&] { read_flat_pattern<16, 1, 1, 1><<<256, 1024>>>(d, nw, w, out); });
+      snprintf(name, sizeof name, "flat pattern %6u B windows, 32 lanes, phase by wavefront", w);
+      timeit(name, bytes, [&] { read_flat_pattern<32, 1, 1, 1><<<256, 1024>>>(d, nw, w, out); });
+      snprintf(name, sizeof name, "flat pattern %6u B windows,  8 lanes, power-of-two tails", w);
+      timeit(name, bytes, [&] { read_flat_pattern<8, 1, 1, 3><<<256, 1024>>>(d, nw, w, out); });
+      snprintf(name, sizeof name, "flat pattern %6u B windows, 16 lanes, power-of-two tails", w);
+      timeit(name, bytes, [&] { read_flat_pattern<16, 1, 1, 3><<<256, 1024>>>(d, nw, w, out); });
+      snprintf(name, sizeof name, "flat pattern %6u B windows, 32 lanes, power-of-two tails", w);
+      timeit(name, bytes, [&] { read_flat_pattern<32, 1, 1, 3><<<256, 1024>>>(d, nw, w, out); });
+      snprintf(name, sizeof name, "flat pattern %6u B windows,  8 lanes, 4 phases", w);
+      timeit(name, bytes, [&] { read_flat_pattern<8, 1, 1, 4><<<256, 1024>>>(d, nw, w, out); });
+      snprintf(name, sizeof name, "flat pattern %6u B windows, 32 lanes, 4 phases", w);
+      timeit(name, bytes, [&] { read_flat_pattern<32, 1, 1, 4><<<256, 1024>>>(d, nw, w, out); });
+      snprintf(name, sizeof name, "flat pattern %6u B windows,  8 lanes, 8 phases", w);
+      timeit(name, bytes, [&] { read_flat_pattern<8, 1, 1, 8><<<256, 1024>>>(d, nw, w, out); });
+      snprintf(name, sizeof name, "flat pattern %6u B windows, 32 lanes, 8 phases", w);
+      timeit(name, bytes, [&] { read_flat_pattern<32, 1, 1, 8><<<256, 1024>>>(d, nw, w, out); });
       snprintf(name, sizeof name, "flat pattern %6u B windows,  8 lanes, windows 3 apart", w);
       timeit(name, bytes, [&] { read_flat_pattern<8, 1, 3><<<256, 1024>>>(d, nw, w, out); });
       snprintf(name, sizeof name, "flat pattern %6u B windows,  8 lanes, windows 17 apart", w);
