@@ -413,6 +413,35 @@ def test_reference_TestChecksum(gpu):
 
 
 @pytest.mark.parametrize("t", [oracle.CRC32, oracle.CRC32C])
+def test_reference_TestChecksumByteBuffer(gpu, t):
+    # TestChecksumByteBuffer.java:33-101 checks the engine on "hello world!" and on 1 KiB of random bytes fed one
+    # byte at a time and as the growing prefixes [0, i).  The GPU path has no incremental engine (the window loop is
+    # what it replaces), so the same inputs go in as whole messages: every prefix of the buffer is one window of
+    # one batched call, and the concatenation of all prefixes -- what the reference's cumulative updates spell
+    # out -- is one more.
+    torch, native, L = gpu
+    hello = b"hello world!"
+    assert native.compute(t, 64, hello) == oracle.compute(t, 64, hello)
+    rng = np.random.default_rng(1000 + t)
+    for _ in range(3):
+        buf = rng.integers(0, 256, 1 << 10, dtype=np.uint8)
+        length = int(rng.integers(2, 1 << 10))
+        n = length
+        arr = (native.OzcsChunk * n)()
+        outs = np.zeros((n, 4), dtype=np.uint8)
+        for i in range(n):                      # prefix [0, i + 1)
+            arr[i].data, arr[i].len = buf.ctypes.data, i + 1
+            arr[i].sums, arr[i].sums_cap = outs[i].ctypes.data, 4
+            arr[i].bpc, arr[i].type = 1 << 10, t
+        native.check(L.ozcs_compute_batch(arr, n))
+        engine = oracle.crc32 if t == oracle.CRC32 else oracle.crc32c
+        for i in range(n):
+            assert int.from_bytes(bytes(outs[i]), "big") == engine(buf[:i + 1]), i
+        cumulative = np.concatenate([buf[:i] for i in range(length)])   # update(bytes, 0, i) for i < length, no reset
+        assert native.compute(t, len(cumulative), cumulative) == engine(cumulative).to_bytes(4, "big")
+
+
+@pytest.mark.parametrize("t", [oracle.CRC32, oracle.CRC32C])
 def test_reference_TestChecksumImplsComputeSameValues(gpu, t):
     # TestChecksumImplsComputeSameValues.java:38-101: 64 MiB of random bytes, six window sizes, every engine must
     # give the same value for every window.  Here the engines are the GPU kernels (host-pointer call and
