@@ -292,6 +292,10 @@ def main():
         }
         if prof_note:
             out["roofline"]["traffic_note"] = prof_note
+        # whole job against the HBM of all GPUs that took part (host-timed, launch gaps included); the per-kernel
+        # figures above are rank 0's
+        out["aggregate_hbm"] = {"achieved": round(value, 1), "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
+                                "frac": round(value / (HBM_PEAK_GBPS * world), 4), "n_gpus": world}
         if args.type in ("SHA256", "MD5"):
             # The bound that matters for the digests: vector-instruction issue.  One lane hashes one window, 64 windows
             # per wavefront; a window of w bytes is (w + 8) // 64 + 1 blocks (data + padding).

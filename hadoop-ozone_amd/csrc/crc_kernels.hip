@@ -52,13 +52,16 @@ constexpr uint32_t kWaveBytes = 2048;  // bytes of a stripe one wavefront covers
 constexpr uint32_t kMainBytes = 4u * 256u * 32u * 4u;          // 128 KiB: 4 byte tables x 32 copies
 constexpr int kNibOps = 14;                                    // operators 0..13 of kOpBytes
 constexpr uint32_t kNibOpBytes = 8u * 16u * 4u;                // 512 B per operator
-constexpr uint32_t kNibOff = kMainBytes;
+// byte tables of the "advance 4 bytes" operator (entry b of table j at kZ4Off + j*1024 + b*4): the small-window
+// kernels merge the four accumulators of a unit with it.  The area starts on a 64 KiB boundary so that a lookup
+// address is the area's upper half-word over a 16-bit index, which one sub-dword shift writes (z4_step).
+constexpr uint32_t kZ4Off = kMainBytes;
+constexpr uint32_t kZ4Bytes = 4u * 256u * 4u;
+static_assert((kZ4Off & 0xffffu) == 0, "z4_step keeps the area's address in the upper half of its address registers");
+constexpr uint32_t kNibOff = kZ4Off + kZ4Bytes;
+static_assert((kNibOff & 0xffu) == 0, "nib_apply takes bytes 1..2 of the table area's address");
 constexpr uint32_t kPartOff = kNibOff + kNibOps * kNibOpBytes;  // 2 x 16 partial registers
-// byte tables of the "advance 4 bytes" operator in 4 copies (entry b of table j, copy r at
-// kZ4Off + j*4096 + b*16 + r*4): the small-window kernels merge the four accumulators of a unit with it
-constexpr uint32_t kZ4Off = (kPartOff + 2u * kWaves * 4u + 15u) & ~15u;
-constexpr uint32_t kZ4Bytes = 4u * 256u * 4u * 4u;
-constexpr uint32_t kLdsBytes = kZ4Off + kZ4Bytes;
+constexpr uint32_t kLdsBytes = kPartOff + 2u * kWaves * 4u;
 static_assert(kLdsBytes <= 160u * 1024u, "one workgroup's tables must fit the CU's 160 KiB of LDS");
 
 __device__ __forceinline__ uint32_t lds_u32(const char* base, uint32_t off) {
@@ -237,7 +240,7 @@ __device__ __forceinline__ void build_tables(char* lds, const PolyBasis& pb, int
     uint32_t z = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) z ^= ((b >> i) & 1) ? pb.op[kOpZ4].v[8 * j + i] : 0u;
-    *reinterpret_cast<uint4*>(lds + kZ4Off + (j * 256 + b) * 16) = make_uint4(z, z, z, z);
+    *reinterpret_cast<uint32_t*>(lds + kZ4Off + (j * 256 + b) * 4) = z;
   }
   for (int e = tid; e < kNibOps * 128; e += kThreads) {
     const int op = e >> 7, q = (e >> 4) & 7, nv = e & 15;
@@ -293,28 +296,42 @@ __device__ __forceinline__ uint32_t slot_fold(const char* lds, const Acc4& a) {
          nib_apply(lds, kOpZ4, a.a3);
 }
 
-// x * x^32 mod P ^ nxt through the byte tables of the 4-byte operator: four lookups and eight vector
-// instructions against eight lookups and some twenty for a nibble-table operator.  The four copies do not
-// remove bank conflicts (about three cycles per lookup on random bytes), which the saved instructions outweigh
-// for windows of a few KiB and less.  z4base = kZ4Off + 4 * (lane & 3).
-__device__ __forceinline__ uint32_t z4_step(const char* lds, uint32_t z4base, uint32_t x, uint32_t nxt) {
-  const uint32_t o0 = ((x & 0xffu) << 4) + z4base;
-  const uint32_t o1 = (__builtin_amdgcn_ubfe(x, 8, 8) << 4) + z4base;
-  const uint32_t o2 = (__builtin_amdgcn_ubfe(x, 16, 8) << 4) + z4base;
-  const uint32_t o3 = ((x >> 24) << 4) + z4base;
-  const uint32_t t0 = lds_u32(lds, o0), t1 = lds_u32(lds, o1 + 4096u), t2 = lds_u32(lds, o2 + 8192u),
-                 t3 = lds_u32(lds, o3 + 12288u);
+// The four LDS addresses one z4_step looks up, kept in registers whose upper half-word holds the table area's
+// address for good: every step rewrites only the lower half-word.
+struct Z4Addr {
+  uint32_t o0, o1, o2, o3;
+};
+__device__ __forceinline__ Z4Addr z4_addr_init() { return Z4Addr{kZ4Off, kZ4Off, kZ4Off, kZ4Off}; }
+
+// x * x^32 mod P ^ nxt through the byte tables of the 4-byte operator: four lookups and six vector instructions
+// against eight lookups and some twenty for a nibble-table operator.  Each address is ONE instruction: a
+// sub-dword shift takes byte k of x, times four, into the lower half-word of the address register and leaves
+// the upper half-word (the area's address) alone; the table's offset rides in the load's immediate.  One copy of
+// the tables: random bytes meet in a bank about 3.5 deep, which the saved instructions outweigh for windows of a
+// few KiB and less.
+__device__ __forceinline__ uint32_t z4_step(const char* lds, Z4Addr& ad, uint32_t x, uint32_t nxt) {
+  const uint32_t two = 2u;
+  asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_0"
+      : "+v"(ad.o0) : "v"(two), "v"(x));
+  asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_1"
+      : "+v"(ad.o1) : "v"(two), "v"(x));
+  asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_2"
+      : "+v"(ad.o2) : "v"(two), "v"(x));
+  asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_3"
+      : "+v"(ad.o3) : "v"(two), "v"(x));
+  const uint32_t t0 = lds_u32(lds, ad.o0), t1 = lds_u32(lds, ad.o1 + 1024u), t2 = lds_u32(lds, ad.o2 + 2048u),
+                 t3 = lds_u32(lds, ad.o3 + 3072u);
   return xor3(xor3(t0, t1, t2), t3, nxt);
 }
 // slot_fold as a Horner chain over the unit's four accumulators: (((a0 z + a1) z + a2) z + a3) z, z = x^32.
-__device__ __forceinline__ uint32_t slot_fold_chain(const char* lds, uint32_t z4base, const Acc4& a) {
+__device__ __forceinline__ uint32_t slot_fold_chain(const char* lds, Z4Addr& ad, const Acc4& a) {
 #ifdef OZCS_SLOT_NIBBLE  // A/B build: the nibble-table form
   return slot_fold(lds, a);
 #endif
-  uint32_t x = z4_step(lds, z4base, a.a0, a.a1);
-  x = z4_step(lds, z4base, x, a.a2);
-  x = z4_step(lds, z4base, x, a.a3);
-  return z4_step(lds, z4base, x, 0u);
+  uint32_t x = z4_step(lds, ad, a.a0, a.a1);
+  x = z4_step(lds, ad, x, a.a2);
+  x = z4_step(lds, ad, x, a.a3);
+  return z4_step(lds, ad, x, 0u);
 }
 
 // Folds the accumulators of a wavefront's two rows.  The result, valid in lane 63, is the register a
@@ -507,9 +524,9 @@ __device__ __forceinline__ void subwave_pair(const char* lds, uint32_t lb01, uin
   // whose low i+1 bits are all ones (they take in the lane 2^i below).  That leaves the lanes below idle:
   // they advance row B's values in the same instruction stream, and the result moves up by one DPP shift.
   // Lanes outside that pattern end up with values nobody reads.
-  const uint32_t z4base = kZ4Off + 4u * (uint32_t)(sl & 3);
-  x = slot_fold_chain(lds, z4base, a);
-  y = slot_fold_chain(lds, z4base, b);
+  Z4Addr za = z4_addr_init(), zb = z4_addr_init();  // one set per row: the two chains interleave
+  x = slot_fold_chain(lds, za, a);
+  y = slot_fold_chain(lds, zb, b);
 #pragma unroll
   for (int i = 0; i < kLevels; i++) {
     const bool taker = (sl & ((2 << i) - 1)) == (2 << i) - 1;
@@ -660,67 +677,114 @@ __global__ __launch_bounds__(kThreads) void crc_flat_kernel(const CrcLaunch p) {
   const uint64_t last = p.n_windows - 1;
   // PH > 1: this wavefront starts `phase` bytes into each of its windows and wraps round (bpc is then a power of
   // two and a multiple of PH load groups); the part behind the phase is the window's tail, read first
-  const uint32_t phase = PH > 1 ? (uint32_t)(wave & (PH - 1)) * (p.bpc / PH) : 0u;
+  // (the wavefront's number is the same in all its lanes: taken from the first lane it is a scalar, and with it the
+  // whole loop control below)
+  const uint32_t phase = PH > 1 ? (uint32_t)(__builtin_amdgcn_readfirstlane(wave) & (PH - 1)) * (p.bpc / PH) : 0u;
   const uint32_t init0 = phase == 0 ? init : 0u;
+  Z4Addr za = z4_addr_init(), zb = z4_addr_init();  // one set per row: the two chains interleave
 
   for (uint64_t w0 = ((uint64_t)blockIdx.x * kWaves + wave) * kWinPerWave; w0 < p.n_windows;
        w0 += (uint64_t)gridDim.x * kWaves * kWinPerWave) {
     const uint64_t ga = w0 + grp, gb = w0 + kWinPerRow + grp;
     const uintptr_t wa = base + (ga < last ? ga : last) * p.bpc, wb = base + (gb < last ? gb : last) * p.bpc;
     uint4 ca[UNR], cb[UNR], na[UNR], nb[UNR];
-    uint32_t off = phase;  // offset of the load group in hand
-#pragma unroll
-    for (int k = 0; k < UNR; k++) {
-      ca[k] = ld16(wa + off + k * kStripe);
-      cb[k] = ld16(wb + off + k * kStripe);
-    }
-    uint32_t noff = off + kGroup;  // offset of the load group in flight
-    if (PH > 1 && noff == p.bpc) noff = 0;
-    if (p.bpc > kGroup) {
-#pragma unroll
-      for (int k = 0; k < UNR; k++) {
-        na[k] = ld16(wa + noff + k * kStripe);
-        nb[k] = ld16(wb + noff + k * kStripe);
-      }
-    }
-    Acc4 a = {ca[0].x ^ init0, ca[0].y, ca[0].z, ca[0].w}, b = {cb[0].x ^ init0, cb[0].y, cb[0].z, cb[0].w};
+    Acc4 a, b;
     Acc4 ta = {0, 0, 0, 0}, tb = {0, 0, 0, 0};  // PH > 1: the accumulators of the tail, parked at the wrap
-#pragma unroll
-    for (int k = 1; k < UNR; k++) {
-      absorb(lds, lb01, lb23, a, ca[k]);
-      absorb(lds, lb01, lb23, b, cb[k]);
-    }
-    for (uint32_t done = kGroup; done < p.bpc; done += kGroup) {
-      off = noff;
+    if (PH == 1) {
+      uintptr_t ua = wa, ub = wb;
 #pragma unroll
       for (int k = 0; k < UNR; k++) {
-        ca[k] = na[k];
-        cb[k] = nb[k];
+        ca[k] = ld16(ua + k * kStripe);
+        cb[k] = ld16(ub + k * kStripe);
       }
-      if (done + kGroup < p.bpc) {
-        noff = off + kGroup;
-        if (PH > 1 && noff == p.bpc) noff = 0;
+      if (p.bpc > kGroup) {
+        ua += kGroup;
+        ub += kGroup;
 #pragma unroll
         for (int k = 0; k < UNR; k++) {
-          na[k] = ld16(wa + noff + k * kStripe);
-          nb[k] = ld16(wb + noff + k * kStripe);
+          na[k] = ld16(ua + k * kStripe);
+          nb[k] = ld16(ub + k * kStripe);
         }
       }
-      if (PH > 1 && off == 0) {  // wrapped round: the window's head starts here, on accumulators of its own
-        ta = a;
-        tb = b;
-        a = {ca[0].x ^ init, ca[0].y, ca[0].z, ca[0].w};
-        b = {cb[0].x ^ init, cb[0].y, cb[0].z, cb[0].w};
+      a = {ca[0].x ^ init, ca[0].y, ca[0].z, ca[0].w};
+      b = {cb[0].x ^ init, cb[0].y, cb[0].z, cb[0].w};
 #pragma unroll
-        for (int k = 1; k < UNR; k++) {
+      for (int k = 1; k < UNR; k++) {
+        absorb(lds, lb01, lb23, a, ca[k]);
+        absorb(lds, lb01, lb23, b, cb[k]);
+      }
+      for (uint32_t done = kGroup; done < p.bpc; done += kGroup) {
+#pragma unroll
+        for (int k = 0; k < UNR; k++) {
+          ca[k] = na[k];
+          cb[k] = nb[k];
+        }
+        if (done + kGroup < p.bpc) {
+          ua += kGroup;
+          ub += kGroup;
+#pragma unroll
+          for (int k = 0; k < UNR; k++) {
+            na[k] = ld16(ua + k * kStripe);
+            nb[k] = ld16(ub + k * kStripe);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < UNR; k++) {
           absorb(lds, lb01, lb23, a, ca[k]);
           absorb(lds, lb01, lb23, b, cb[k]);
         }
-      } else {
+      }
+    } else {
+      // Two buffers of load groups take turns (the window holds an even number of groups), so that nothing is
+      // copied from "next" to "current"; all offsets and conditions are scalars.
+      auto load = [&](uint4 (&da)[UNR], uint4 (&db)[UNR], uint32_t off) {
 #pragma unroll
         for (int k = 0; k < UNR; k++) {
-          absorb(lds, lb01, lb23, a, ca[k]);
-          absorb(lds, lb01, lb23, b, cb[k]);
+          da[k] = ld16(wa + off + k * kStripe);
+          db[k] = ld16(wb + off + k * kStripe);
+        }
+      };
+      auto consume = [&](const uint4 (&da)[UNR], const uint4 (&db)[UNR], uint32_t off) {
+        if (off == 0) {  // wrapped round: the window's head starts here, on accumulators of its own
+          ta = a;
+          tb = b;
+          a = {da[0].x ^ init, da[0].y, da[0].z, da[0].w};
+          b = {db[0].x ^ init, db[0].y, db[0].z, db[0].w};
+#pragma unroll
+          for (int k = 1; k < UNR; k++) {
+            absorb(lds, lb01, lb23, a, da[k]);
+            absorb(lds, lb01, lb23, b, db[k]);
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < UNR; k++) {
+            absorb(lds, lb01, lb23, a, da[k]);
+            absorb(lds, lb01, lb23, b, db[k]);
+          }
+        }
+      };
+      auto next = [&](uint32_t off) { return off + kGroup == p.bpc ? 0u : off + kGroup; };
+      uint32_t oc = phase, on = next(phase);  // offsets of the groups in ca/cb and in na/nb
+      load(ca, cb, oc);
+      load(na, nb, on);
+      a = {ca[0].x ^ init0, ca[0].y, ca[0].z, ca[0].w};
+      b = {cb[0].x ^ init0, cb[0].y, cb[0].z, cb[0].w};
+#pragma unroll
+      for (int k = 1; k < UNR; k++) {
+        absorb(lds, lb01, lb23, a, ca[k]);
+        absorb(lds, lb01, lb23, b, cb[k]);
+      }
+      for (uint32_t done = kGroup; done < p.bpc; done += 2 * kGroup) {  // an odd number of groups is left
+        const bool more = done + kGroup < p.bpc;
+        if (more) {
+          oc = next(on);
+          load(ca, cb, oc);
+        }
+        consume(na, nb, on);
+        if (more) {
+          on = next(oc);
+          if (done + 2 * kGroup < p.bpc) load(na, nb, on);
+          consume(ca, cb, oc);
         }
       }
     }
@@ -743,8 +807,7 @@ __global__ __launch_bounds__(kThreads) void crc_flat_kernel(const CrcLaunch p) {
 #pragma unroll
       for (int k = 0; k < 8; k++) *va[k] ^= vt[k];
     }
-    const uint32_t z4base = kZ4Off + 4u * (uint32_t)(sl & 3);
-    uint32_t x = slot_fold_chain(lds, z4base, a), y = slot_fold_chain(lds, z4base, b);
+    uint32_t x = slot_fold_chain(lds, za, a), y = slot_fold_chain(lds, zb, b);
 #pragma unroll
     for (int i = 0; i < kLevels; i++) {  // as in crc_subwave_kernel
       const bool taker = (sl & ((2 << i) - 1)) == (2 << i) - 1;
@@ -941,7 +1004,7 @@ hipError_t crc_launch(const CrcLaunch& launch, int mode, int group, int num_cus,
   }
   const uint64_t per_block = kWaves / group;
   uint64_t blocks = (p.n_windows + per_block - 1) / per_block;
-  if (blocks > (uint64_t)num_cus) blocks = num_cus;  // 138 KiB of LDS: one block per CU, persistent
+  if (blocks > (uint64_t)num_cus) blocks = num_cus;  // 139 KiB of LDS: one block per CU, persistent
   // Default: one stripe ahead.  Deeper prefetch measured slower on MI355X (the kernel is limited by
   // the clock the chip holds under this LDS + HBM load, and more registers in flight cost more).
   switch (g_force_pf) {

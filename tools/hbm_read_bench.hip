@@ -104,7 +104,7 @@ __global__ __launch_bounds__(1024) void read_crc_pattern(const uint8_t* p, uint6
 
 // the small-window CRC kernels' pattern: LPW lanes share a window (a load instruction gathers 64/LPW pieces of
 // 16*LPW bytes, one per window, `win` bytes apart), two rows of windows per wavefront, one stripe group ahead;
-// with LDS != 0 the workgroup also holds 154 KiB of LDS like the CRC kernels (one workgroup per CU)
+// with LDS != 0 the workgroup also holds 154 KiB of LDS (more than half a CU, as the CRC kernels do) (one workgroup per CU)
 // SPREAD (odd): logical window g is physical window (g * SPREAD) mod nwin, nwin a power of two -- the windows one
 // wavefront reads together are then SPREAD windows apart instead of adjacent
 // PHASE: every wavefront starts its windows at an offset of its own and wraps round (1: by wavefront number, 2: by
