@@ -9,10 +9,13 @@
 //   write path  BlockOutputStream.writeChunkToContainer over BufferPool buffers
 //               hadoop-hdds/client/src/main/java/org/apache/hadoop/hdds/scm/storage/BlockOutputStream.java:495-507, 645-690
 //               hadoop-hdds/client/src/main/java/org/apache/hadoop/hdds/scm/storage/BufferPool.java:74-85
+//               BlockOutputStream.write / flush / close (:225-266, :405-473) over those buffers
 // Header-only; link libozcs.so.
 #pragma once
 #include <algorithm>
 #include <cstdio>
+#include <cstring>
+#include <deque>
 #include <functional>
 #include <string>
 #include <utility>
@@ -185,6 +188,150 @@ class PinnedChunkPool {
   ChecksumType type_;
   int bpc_;
   std::vector<std::string> outs_;  // per slot: where the pipe delivers the digests of the slot's current ticket
+};
+
+// BlockOutputStream's data path around the checksum call
+// (hadoop-hdds/client/src/main/java/org/apache/hadoop/hdds/scm/storage/BlockOutputStream.java):
+//   write / writeChunkIfNeeded   :225-266   bytes go into the current chunk buffer; a full buffer becomes a chunk
+//   writeChunkToContainer        :645-690   offset bookkeeping, computeChecksum(chunk), the ChunkInfo record (name
+//                                           "<localID>_chunk_<n>", offset, len, checksumData), writeChunkAsync
+//   flush / close                :405-473   the partly filled buffer goes out as a last, shorter chunk
+// The chunk buffers are the pinned slots of an ozcs pipe (in place of BufferPool's heap buffers): a full buffer is
+// submitted and the writer goes on filling the next one while the first is copied and hashed; chunks are handed to
+// writeChunkAsync strictly in order, each as soon as its digests have arrived.  What comes out -- the ChunkInfo
+// records and the bytes -- is what the reference would ship.
+class BlockOutputStream {
+ public:
+  using WriteChunkAsync = std::function<void(const ChunkInfo&, const char* data, size_t len)>;
+
+  // capacity = streamBufferMaxSize / streamBufferSize, the number of chunk buffers
+  // (BlockOutputStreamEntryPool.java:91-96).
+  BlockOutputStream(long long localID, WriteChunkAsync writeChunkAsync, const OzoneClientConfig& config = OzoneClientConfig(),
+                    uint64_t streamBufferSize = 4u << 20, uint32_t capacity = 8, int device = 0)
+      : localID_(localID), sink_(std::move(writeChunkAsync)), type_(config.getChecksumType()),
+        bpc_(config.getBytesPerChecksum()), bufferSize_(streamBufferSize) {
+    const int t = (int)type_;
+    if (t < OZCS_NONE || t > OZCS_MD5) throw OzoneChecksumException(type_);
+    const int rc = ozcs_pipe_create(device, capacity, streamBufferSize, &pipe_);
+    if (rc != OZCS_OK) throw GpuUnavailable(rc, std::string("ozcs_pipe_create: ") + ozcs_last_error());
+  }
+  ~BlockOutputStream() {
+    try {
+      close();
+    } catch (...) {
+    }
+  }
+  BlockOutputStream(const BlockOutputStream&) = delete;
+  BlockOutputStream& operator=(const BlockOutputStream&) = delete;
+
+  // write(byte[], off, len), :241-266
+  void write(const void* b, size_t len) {
+    checkOpen();
+    const char* src = static_cast<const char*>(b);
+    while (len > 0) {
+      allocateNewBufferIfNeeded();
+      const size_t n = std::min<size_t>(bufferSize_ - pos_, len);
+      std::memcpy(static_cast<char*>(cur_) + pos_, src, n);
+      pos_ += n;
+      if (pos_ == bufferSize_) writeChunk();
+      src += n;
+      len -= n;
+      writtenDataLength_ += (long long)n;
+    }
+  }
+  // The data buffered so far goes out (handleFlush: a partly filled buffer becomes a chunk of its own) and every
+  // submitted chunk is shipped.
+  void flush() {
+    checkOpen();
+    if (cur_ && pos_ > 0) writeChunk();
+    while (!pending_.empty()) shipOldest();
+  }
+  void close() {
+    if (closed_) return;
+    struct Finally {
+      BlockOutputStream* s;
+      ~Finally() {
+        s->closed_ = true;
+        if (s->cur_) {  // acquired, never filled: give it back through an empty submission
+          (void)ozcs_pipe_submit_slot(s->pipe_, s->curTicket_, OZCS_NONE, 1, 0, nullptr, 0);
+          (void)ozcs_pipe_wait(s->pipe_, s->curTicket_, nullptr);
+          s->cur_ = nullptr;
+        }
+        ozcs_pipe_destroy(s->pipe_);
+        s->pipe_ = nullptr;
+      }
+    } fin{this};
+    flush();
+  }
+  long long getWrittenDataLength() const { return writtenDataLength_; }
+  // containerBlockData's chunk list, in order
+  const std::vector<ChunkInfo>& getChunks() const { return chunks_; }
+
+ private:
+  struct Pending {
+    int ticket;
+    ChunkInfo info;
+    const char* data;
+    std::string sums;
+    uint64_t nsums;
+  };
+  void checkOpen() const {
+    if (closed_) throw std::runtime_error("BlockOutputStream has been closed.");
+  }
+  void allocateNewBufferIfNeeded() {  // :281-286 over BufferPool.allocateBuffer
+    if (cur_) return;
+    int rc;
+    while ((rc = ozcs_pipe_acquire(pipe_, &cur_, &curTicket_)) == OZCS_EBUSY)
+      shipOldest();  // every buffer is in flight: the reference waits for acknowledgements here (handleFullBuffer)
+    if (rc != OZCS_OK) throw GpuUnavailable(rc, std::string("ozcs_pipe_acquire: ") + ozcs_last_error());
+    pos_ = 0;
+  }
+  void writeChunk() {  // writeChunk + writeChunkToContainer, :495-507, :645-690
+    const uint64_t n = pos_;
+    const long long offset = chunkOffset_;
+    chunkOffset_ += (long long)n;
+    chunkIndex_++;
+    const int t = (int)type_;
+    const uint64_t nsums = type_ == ChecksumType::NONE ? 0 : ozcs_num_checksums(n, (uint32_t)bpc_);
+    pending_.push_back(Pending{curTicket_, ChunkInfo(std::to_string(localID_) + "_chunk_" + std::to_string(chunkIndex_), offset, (long long)n),
+                               static_cast<const char*>(cur_), std::string((size_t)(nsums * ozcs_digest_size(t)), '\0'), nsums});
+    Pending& p = pending_.back();  // std::deque: the digest buffer does not move while the kernel writes it
+    const int rc = ozcs_pipe_submit_slot(pipe_, p.ticket, t, (uint32_t)bpc_, n, p.sums.empty() ? nullptr : &p.sums[0], p.sums.size());
+    if (rc != OZCS_OK) {
+      pending_.pop_back();
+      throw GpuUnavailable(rc, std::string("ozcs_pipe_submit_slot: ") + ozcs_last_error());
+    }
+    cur_ = nullptr;
+  }
+  void shipOldest() {
+    Pending& p = pending_.front();
+    uint64_t got = 0;
+    const int rc = ozcs_pipe_wait(pipe_, p.ticket, &got);
+    if (rc != OZCS_OK) throw GpuUnavailable(rc, std::string("ozcs_pipe_wait: ") + ozcs_last_error());
+    const size_t ds = ozcs_digest_size((int)type_);
+    std::vector<ByteString> sums;
+    for (uint64_t i = 0; i < got; i++) sums.emplace_back(p.sums.substr((size_t)i * ds, ds));
+    p.info.setChecksumData(ChecksumData(type_, bpc_, std::move(sums)));
+    chunks_.push_back(p.info);
+    // the slot is free again, but only this stream acquires from the pipe: its bytes stay until the next write
+    sink_(chunks_.back(), p.data, (size_t)p.info.getLen());
+    pending_.pop_front();
+  }
+
+  long long localID_;
+  WriteChunkAsync sink_;
+  ChecksumType type_;
+  int bpc_;
+  uint64_t bufferSize_;
+  ozcs_pipe* pipe_ = nullptr;
+  void* cur_ = nullptr;  // the buffer being filled and its ticket
+  int curTicket_ = -1;
+  uint64_t pos_ = 0;
+  long long chunkOffset_ = 0, writtenDataLength_ = 0;
+  int chunkIndex_ = 0;
+  bool closed_ = false;
+  std::deque<Pending> pending_;  // submitted chunks not yet shipped
+  std::vector<ChunkInfo> chunks_;
 };
 
 }  // namespace ozone

@@ -5,6 +5,7 @@
 #include <cstring>
 #include <unistd.h>
 #include <utility>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -314,6 +315,55 @@ int main() {
     for (auto& b : parts) b->rewind();
     ChunkBufferImplWithByteBufferList every(parts, false);
     EXPECT(ck.computeChecksum(every).getChecksums() == want);
+  }
+  // BlockOutputStream over the pinned pipe, in the shape of TestBlockOutputStreamCorrectness.java: seeded bytes
+  // written in odd pieces; what reaches writeChunkAsync is the same bytes cut into chunks of the buffer size, each
+  // with the ChunkInfo the reference builds (BlockOutputStream.java:645-656), checksums included
+  for (const char* typeName : {"CRC32", "SHA256", "NONE"}) {
+    typedef std::map<std::string, std::string> Conf;
+    OzoneClientConfig cfg(Conf{{"ozone.client.checksum.type", typeName}, {"ozone.client.bytes.per.checksum", "256KB"}});
+    const size_t total = 6 * (1u << 20) + 12345;
+    std::string payload(total, '\0');
+    oracle_fill_splitmix64(2024, (uint8_t*)&payload[0], payload.size());
+    std::vector<std::pair<ChunkInfo, std::string>> shipped;
+    {
+      BlockOutputStream out(777, [&](const ChunkInfo& info, const char* d, size_t n) { shipped.emplace_back(info, std::string(d, n)); },
+                            cfg, 1u << 20, 3);
+      const size_t pieces[5] = {1, 4099, 600001, 77, 262144};
+      size_t pos = 0;
+      for (int k = 0; pos < total; k++) {
+        const size_t n = std::min(total - pos, pieces[k % 5]);
+        out.write(payload.data() + pos, n);
+        pos += n;
+      }
+      out.close();
+      EXPECT(out.getWrittenDataLength() == (long long)total);
+      EXPECT(out.getChunks().size() == 7);
+      try {
+        out.write("x", 1);
+        EXPECT(!"write after close accepted");
+      } catch (const std::runtime_error&) {
+      }
+    }
+    EXPECT(shipped.size() == 7);
+    std::string joined;
+    long long off = 0;
+    for (size_t i = 0; i < shipped.size(); i++) {
+      const ChunkInfo& info = shipped[i].first;
+      const std::string& d = shipped[i].second;
+      joined += d;
+      EXPECT(d.size() == (i < 6 ? (1u << 20) : 12345u));
+      EXPECT(info.getChunkName() == "777_chunk_" + std::to_string(i + 1));
+      EXPECT(info.getOffset() == off && info.getLen() == (long long)d.size());
+      const ChecksumData& cd = info.getChecksumData();
+      EXPECT(cd.getChecksumType() == cfg.getChecksumType() && cd.getBytesPerChecksum() == 262144);
+      if (cfg.getChecksumType() == ChecksumType::NONE) EXPECT(cd.getChecksums().empty());
+      else EXPECT(cd.getChecksums() == oracle_sums(cfg.getChecksumType(), 262144, d));
+      const ChunkInfo back = ChunkInfo::getFromProtoBuf(info.getProtoBufMessage());  // WriteChunkRequestProto.chunkData
+      EXPECT(back.getChecksumData() == cd && back.getOffset() == off);
+      off += (long long)d.size();
+    }
+    EXPECT(joined == payload);
   }
   std::printf(failures ? "%d FAILURES\n" : "host mirror: all passed\n", failures);
   ozcs_shutdown();
