@@ -83,34 +83,38 @@ inline std::string chunkInfoToString(const std::string& chunkName, long long off
 // raises the length form (:314-320), one that ends inside a window fails that window first.
 // throttler may be empty (a caller that cancels binds its canceler into it, as DataTransferThrottler.throttle(v,
 // canceler) receives it).  Returns the number of bytes read.
-inline long long verifyChunkFile(const std::string& blockId, const std::string& chunkName, long long chunkOffset,
-                                 long long chunkLen, const ChecksumData& checksumData, const std::string& chunkFile,
-                                 ChunkLayOutVersion layout, const std::function<void(long long)>& throttler = {}) {
-  const std::vector<ByteString>& sums = checksumData.getChecksums();
-  const long long count = (long long)sums.size();
+namespace detail {
+
+// What the scrubber reads of one chunk: whole windows up to the stored count, FILE_PER_BLOCK positioned at the
+// chunk's offset and never past the chunk (KeyValueContainerCheck.java:276-285).
+inline std::string readChunkWindows(long long chunkOffset, long long chunkLen, const ChecksumData& checksumData,
+                                    const std::string& chunkFile, ChunkLayOutVersion layout) {
+  const long long count = (long long)checksumData.getChecksums().size();
   const long long bpc = checksumData.getBytesPerChecksum();
   long long want = count * bpc;
   if (layout == ChunkLayOutVersion::FILE_PER_BLOCK && count && chunkLen % bpc != 0) want = (count - 1) * bpc + chunkLen % bpc;
   std::string data((size_t)want, '\0');
   long long nRead = 0;
-  {
-    FILE* f = std::fopen(chunkFile.c_str(), "rb");
-    if (!f) throw std::runtime_error("cannot open " + chunkFile);
-    if (layout == ChunkLayOutVersion::FILE_PER_BLOCK) std::fseek(f, (long)chunkOffset, SEEK_SET);
-    if (want) nRead = (long long)std::fread(&data[0], 1, (size_t)want, f);
-    std::fclose(f);
-  }
+  FILE* f = std::fopen(chunkFile.c_str(), "rb");
+  if (!f) throw std::runtime_error("cannot open " + chunkFile);
+  if (layout == ChunkLayOutVersion::FILE_PER_BLOCK) std::fseek(f, (long)chunkOffset, SEEK_SET);
+  if (want) nRead = (long long)std::fread(&data[0], 1, (size_t)want, f);
+  std::fclose(f);
+  data.resize((size_t)nRead);
+  return data;
+}
+
+// The reference's order of events, replayed over a verdict the GPU has already given (`first` = first failing
+// window or -1): window i is throttled, then judged, and the first failing window ends the scan (:294-311) -- the
+// throttler never sees a window behind the failure; then the length check (:314-320).
+inline long long replayChunk(const std::string& blockId, const std::string& chunkName, long long chunkOffset, long long chunkLen,
+                             const ChecksumData& checksumData, const std::string& data, int64_t first,
+                             const std::function<void(long long)>& throttler) {
+  const std::vector<ByteString>& sums = checksumData.getChecksums();
+  const long long bpc = checksumData.getBytesPerChecksum();
+  const long long nRead = (long long)data.size();
   const long long windowsRead = bpc ? (nRead + bpc - 1) / bpc : 0;
   const ChecksumType type = checksumData.getChecksumType();
-  int64_t first = -1;
-  if (type != ChecksumType::NONE && windowsRead) {  // all windows hashed and compared by one call
-    std::string stored;
-    for (long long i = 0; i < windowsRead; i++) stored += sums[(size_t)i];
-    const int rc = ozcs_verify((int)type, (uint32_t)bpc, data.data(), (uint64_t)nRead, stored.data(), (uint64_t)windowsRead, 0, &first);
-    if (rc != OZCS_OK) throw OzoneChecksumException(std::string(ozcs_last_error()));
-  }
-  // the reference's order of events, replayed: window i is throttled, then judged, and the first failing window
-  // ends the scan (:294-311) -- the throttler never sees a window behind the failure
   for (long long i = 0; i < windowsRead; i++) {
     if (throttler) throttler(std::min(bpc, nRead - i * bpc));
     if (type == ChecksumType::NONE)  // computeChecksum yields no checksums for NONE: getChecksums().get(0) throws (:297-298)
@@ -128,6 +132,77 @@ inline long long verifyChunkFile(const std::string& blockId, const std::string& 
     throw OzoneChecksumException("Inconsistent read for chunk=" + chunkName + " expected length=" + std::to_string(chunkLen) +
                                  " actual length=" + std::to_string(nRead) + " for block " + blockId);
   return nRead;
+}
+
+}  // namespace detail
+
+inline long long verifyChunkFile(const std::string& blockId, const std::string& chunkName, long long chunkOffset,
+                                 long long chunkLen, const ChecksumData& checksumData, const std::string& chunkFile,
+                                 ChunkLayOutVersion layout, const std::function<void(long long)>& throttler = {}) {
+  const std::vector<ByteString>& sums = checksumData.getChecksums();
+  const long long bpc = checksumData.getBytesPerChecksum();
+  const std::string data = detail::readChunkWindows(chunkOffset, chunkLen, checksumData, chunkFile, layout);
+  const long long nRead = (long long)data.size();
+  const long long windowsRead = bpc ? (nRead + bpc - 1) / bpc : 0;
+  const ChecksumType type = checksumData.getChecksumType();
+  int64_t first = -1;
+  if (type != ChecksumType::NONE && windowsRead) {  // all windows hashed and compared by one call
+    std::string stored;
+    for (long long i = 0; i < windowsRead; i++) stored += sums[(size_t)i];
+    const int rc = ozcs_verify((int)type, (uint32_t)bpc, data.data(), (uint64_t)nRead, stored.data(), (uint64_t)windowsRead, 0, &first);
+    if (rc != OZCS_OK) throw OzoneChecksumException(std::string(ozcs_last_error()));
+  }
+  return detail::replayChunk(blockId, chunkName, chunkOffset, chunkLen, checksumData, data, first, throttler);
+}
+
+// One chunk of a block as the scrubber sees it: the ChunkInfo record's fields and the file that holds it.
+struct ScrubChunk {
+  std::string chunkName;
+  long long chunkOffset, chunkLen;
+  ChecksumData checksumData;
+  std::string chunkFile;
+};
+
+// The `for chunk in block.getChunks()` loop of KeyValueContainerCheck.scanData (:235-257) with ONE ozcs_verify_batch
+// call for all chunks instead of one checksum call per window.  All chunks are read and hashed in bulk first; then
+// the reference's order of events is replayed chunk by chunk, window by window, so the throttler sees exactly the
+// windows the reference would have read up to the failure and the first chunk (in order) that fails raises what
+// verifyChunkFile raises for it.  Returns the number of bytes read.
+inline long long verifyBlock(const std::string& blockId, const std::vector<ScrubChunk>& chunks, ChunkLayOutVersion layout,
+                             const std::function<void(long long)>& throttler = {}) {
+  std::vector<std::string> reads, stored;
+  std::vector<ozcs_vchunk> v(chunks.size());
+  for (const ScrubChunk& c : chunks) {
+    reads.push_back(detail::readChunkWindows(c.chunkOffset, c.chunkLen, c.checksumData, c.chunkFile, layout));
+    const long long bpc = c.checksumData.getBytesPerChecksum();
+    const long long nwin = bpc ? ((long long)reads.back().size() + bpc - 1) / bpc : 0;
+    std::string s;
+    for (long long i = 0; i < nwin; i++) s += c.checksumData.getChecksums()[(size_t)i];
+    stored.push_back(std::move(s));
+  }
+  for (size_t i = 0; i < chunks.size(); i++) {
+    const long long bpc = chunks[i].checksumData.getBytesPerChecksum();
+    const uint64_t nwin = bpc ? (reads[i].size() + (size_t)bpc - 1) / (size_t)bpc : 0;
+    v[i] = ozcs_vchunk{};
+    v[i].type = nwin ? (int)chunks[i].checksumData.getChecksumType() : OZCS_NONE;  // nothing read: only the length check applies
+    v[i].bpc = (uint32_t)bpc;
+    v[i].data = reads[i].empty() ? nullptr : reads[i].data();
+    v[i].len = reads[i].size();
+    v[i].expected = stored[i].data();
+    v[i].n_expected = nwin;
+  }
+  const int rc = chunks.empty() ? OZCS_OK : ozcs_verify_batch(v.data(), (uint32_t)v.size());
+  long long total = 0;
+  for (size_t i = 0; i < chunks.size(); i++) {
+    if (v[i].status != OZCS_OK) {
+      if (rc == OZCS_ENODEV || rc == OZCS_EHIP || rc == OZCS_ENOMEM)
+        throw GpuUnavailable(v[i].status, std::string("ozcs_verify_batch: ") + ozcs_last_error());
+      throw OzoneChecksumException("verify failed for chunk " + chunks[i].chunkName + ": status " + std::to_string(v[i].status));
+    }
+    total += detail::replayChunk(blockId, chunks[i].chunkName, chunks[i].chunkOffset, chunks[i].chunkLen, chunks[i].checksumData,
+                                 reads[i], v[i].first_mismatch, throttler);
+  }
+  return total;
 }
 
 // ---------------------------------------------------------------------------------------------- write path

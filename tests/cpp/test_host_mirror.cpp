@@ -238,6 +238,44 @@ int main() {
     std::remove(path.c_str());
   }
 
+  // ---- scrubber, a whole block in one batched call: three chunks in one block file, the second corrupt in two
+  // windows; the throttler sees chunk 0 whole and chunk 1 up to its first failing window, nothing behind it ----
+  {
+    const int bpc = 4096;
+    const long long chunkLen = 10 * 4096;
+    std::string file((size_t)(3 * chunkLen), '\0');
+    oracle_fill_splitmix64(600, (uint8_t*)&file[0], file.size());
+    const std::string path = "/tmp/ozcs_cpp_block_" + std::to_string((long long)getpid());
+    auto put = [&](const std::string& bytes) {
+      FILE* f = std::fopen(path.c_str(), "wb");
+      std::fwrite(bytes.data(), 1, bytes.size(), f);
+      std::fclose(f);
+    };
+    std::vector<ScrubChunk> chunks;
+    for (int i = 0; i < 3; i++)
+      chunks.push_back(ScrubChunk{"c" + std::to_string(i), i * chunkLen, chunkLen,
+                                  ChecksumData(ChecksumType::CRC32C, bpc, oracle_sums(ChecksumType::CRC32C, bpc, file.substr((size_t)(i * chunkLen), (size_t)chunkLen))),
+                                  path});
+    put(file);
+    long long throttled = 0;
+    EXPECT(verifyBlock("blk#9", chunks, ChunkLayOutVersion::FILE_PER_BLOCK, [&](long long n) { throttled += n; }) == 3 * chunkLen);
+    EXPECT(throttled == 3 * chunkLen);
+    std::string bad = file;
+    bad[(size_t)(chunkLen + 3 * bpc + 17)] ^= 0x80;  // chunk 1, window 3
+    bad[(size_t)(chunkLen + 7 * bpc)] ^= 0x80;       // and a later window, never reached
+    put(bad);
+    std::vector<long long> seen;
+    try {
+      verifyBlock("blk#9", chunks, ChunkLayOutVersion::FILE_PER_BLOCK, [&](long long n) { seen.push_back(n); });
+      EXPECT(!"corrupt block accepted");
+    } catch (const OzoneChecksumException& e) {
+      const std::string w = e.what();
+      EXPECT(w.find("Inconsistent read for chunk=ChunkInfo{chunkName='c1, offset=40960, len=40960} checksum item 3 expected checksum [") == 0);
+      EXPECT(seen.size() == 10 + 4);   // chunk 0's ten windows, chunk 1's windows 0..3
+    }
+    std::remove(path.c_str());
+  }
+
   // ---- write path: chunks through pinned buffers, checksum overlapped with the next fill ----
   {
     PinnedChunkPool pool(0, 3, 1 << 20, ChecksumType::CRC32C, 65536);
