@@ -227,7 +227,9 @@ int main(int argc, char** argv) {
   const u32x4* p = (const u32x4*)d;
   printf("buffer %llu GiB\n", (unsigned long long)(bytes >> 30));
   if (argc > 2 && !strcmp(argv[2], "flat")) {   // bare reads in the small-window kernels' pattern, window size x lanes per window
-    for (uint32_t w : {512u, 2048u, 4096u, 8192u, 16384u, 32768u, 65536u, 131072u}) {
+    std::vector<uint32_t> sizes = {512u, 2048u, 4096u, 8192u, 16384u, 32768u, 65536u, 131072u};
+    if (argc > 3 && !strcmp(argv[3], "large")) sizes = {262144u, 524288u, 1048576u};
+    for (uint32_t w : sizes) {
       char name[96];
       const uint64_t nw = bytes / w;
       snprintf(name, sizeof name, "flat pattern %6u B windows,  8 lanes, LDS held", w);
