@@ -65,6 +65,18 @@ public final class GpuChecksum {
   public static native long verifyChunkedSumsByteArray(int bytesPerSum, int checksumType,
       byte[] sums, int sumsOffset, int numSums, int startIndex, byte[] data, int dataOffset, int dataLength);
 
+  /** Same for direct buffers (position..limit of data; numSums stored digests from sums.position()).  Shape of
+   *  NativeCRC32Wrapper.verifyChunkedSums; no position moves. */
+  public static long verifyChunkedSums(int bytesPerSum, int checksumType, ByteBuffer sums, int numSums, int startIndex,
+      ByteBuffer data) {
+    return verifyChunkedSumsDirect(bytesPerSum, checksumType, sums, sums.position(), sums.limit(), numSums, startIndex,
+        data, data.position(), data.limit());
+  }
+
+  private static native long verifyChunkedSumsDirect(int bytesPerSum, int checksumType,
+      ByteBuffer sums, int sumsPosition, int sumsLimit, int numSums, int startIndex,
+      ByteBuffer data, int dataPosition, int dataLimit);
+
   // ---- pinned pipeline: replaces BufferPool's heap buffers by pinned direct buffers ----
   public static native long pipeCreate(int device, int slots, long slotBytes);
   public static native void pipeDestroy(long pipe);

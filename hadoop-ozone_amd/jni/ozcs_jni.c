@@ -118,6 +118,23 @@ JNIEXPORT jlong JNICALL JFN(verifyChunkedSumsByteArray)(JNIEnv* env, jclass cls,
   return rc == OZCS_OK ? (jlong)first : (jlong)(-1 + rc);
 }
 
+JNIEXPORT jlong JNICALL JFN(verifyChunkedSumsDirect)(JNIEnv* env, jclass cls, jint bpc, jint type,
+    jobject sums, jint sumsPos, jint sumsLimit, jint numSums, jint startIndex, jobject data, jint dataPos, jint dataLimit) {
+  (void)cls;
+  const uint8_t* d = (const uint8_t*)(*env)->GetDirectBufferAddress(env, data);
+  const uint8_t* s = (const uint8_t*)(*env)->GetDirectBufferAddress(env, sums);
+  if (!d || !s || bpc <= 0 || dataPos < 0 || dataLimit < dataPos || sumsPos < 0 || sumsLimit < sumsPos || numSums < 0 ||
+      startIndex < 0)
+    return -1 + OZCS_EINVAL;
+  if (dataLimit > (*env)->GetDirectBufferCapacity(env, data) || sumsLimit > (*env)->GetDirectBufferCapacity(env, sums))
+    return -1 + OZCS_EINVAL;
+  if ((jlong)numSums * (jlong)ozcs_digest_size(type) > (jlong)(sumsLimit - sumsPos)) return -1 + OZCS_EINVAL;
+  int64_t first = -1;
+  const int rc = ozcs_verify(type, (uint32_t)bpc, d + dataPos, (uint64_t)(dataLimit - dataPos), s + sumsPos, (uint64_t)numSums,
+                             (uint64_t)startIndex, &first);
+  return rc == OZCS_OK ? (jlong)first : (jlong)(-1 + rc);
+}
+
 JNIEXPORT jlong JNICALL JFN(pipeCreate)(JNIEnv* env, jclass cls, jint device, jint slots, jlong slotBytes) {
   (void)env; (void)cls;
   ozcs_pipe* p = NULL;

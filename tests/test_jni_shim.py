@@ -80,6 +80,7 @@ class FakeJvm:
                "calculateChunkedSumsByteArray": (J, [I, I, V, I, V, I, I]),
                "calculateChunkedSumsDirect": (J, [I, I, V, I, I, V, I, I]),
                "verifyChunkedSumsByteArray": (J, [I, I, V, I, I, I, V, I, I]),
+               "verifyChunkedSumsDirect": (J, [I, I, V, I, I, I, I, V, I, I]),
                "pipeCreate": (J, [I, I, J]), "pipeDestroy": (None, [J]), "pipeAcquire": (V, [J, V]),
                "pipeSubmit": (I, [J, I, I, I, J, V]), "pipeWait": (J, [J, I]),
                "pipeNextCompleted": (J, [J, B, V]), "pipeTicketSlot": (I, [I])}
@@ -151,6 +152,15 @@ def test_shim_direct_buffers_and_verify(jvm):
     heap[64 + 5 * bpc + 3] ^= 1
     assert jvm.verifyChunkedSumsByteArray(*args(heap)) == 5
     assert jvm.verifyChunkedSumsByteArray(*args(data, nsums=3)) < -1     # fewer stored sums than windows (OZCS_ERANGE)
+    # the same through direct buffers (positions and limits from the Java side): the stored digests sit at position 8
+    dsums = np.concatenate([np.zeros(8, dtype=np.uint8), stored])
+    dargs = lambda d, lim=64 + n: (bpc, oracle.CRC32C, jvm.obj(K_DIRECT, dsums), 8, dsums.size, len(want) // 4, 0,
+                                   jvm.obj(K_DIRECT, d), 64, lim)
+    assert jvm.verifyChunkedSumsDirect(*dargs(data)) == -1
+    assert jvm.verifyChunkedSumsDirect(*dargs(heap)) == 5
+    assert jvm.verifyChunkedSumsDirect(*dargs(data, lim=data.size + 1)) == -2                      # limit beyond capacity
+    assert jvm.verifyChunkedSumsDirect(bpc, oracle.CRC32C, jvm.obj(K_DIRECT, dsums), 8, 16, len(want) // 4, 0,
+                                       jvm.obj(K_DIRECT, data), 64, 64 + n) == -2                  # digests beyond sums.limit()
     # startIndex: windows 2.. of the chunk against the stored list from index 2
     assert jvm.verifyChunkedSumsByteArray(bpc, oracle.CRC32C, jvm.obj(K_BYTES, stored), 0, len(want) // 4, 2,
                                           jvm.obj(K_BYTES, data), 64 + 2 * bpc, n - 2 * bpc) == -1
