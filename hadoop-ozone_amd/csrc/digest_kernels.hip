@@ -52,7 +52,7 @@ __constant__ const uint32_t kK256[64] = {
 struct Sha256 {
   static constexpr int kWords = 8;
   static constexpr bool kBigEndian = true;
-  static constexpr int kStepBlocks = 1;  // 64-byte blocks fetched per loader step (ALU bound: no need for 2)
+  static constexpr int kStepBlocks = 1;  // 64-byte blocks fetched per loader step (Sha256Lines: 2)
   static __device__ __forceinline__ void init(uint32_t* h) {
     h[0] = 0x6a09e667; h[1] = 0xbb67ae85; h[2] = 0x3c6ef372; h[3] = 0xa54ff53a;
     h[4] = 0x510e527f; h[5] = 0x9b05688c; h[6] = 0x1f83d9ab; h[7] = 0x5be0cd19;
@@ -130,6 +130,13 @@ struct Md5 {
 // 2.5-4 % faster there, but slower when wavefronts are scarce and each runs a long chain alone on its SIMD
 // (2.45 against 3.04 TB/s at 1 MiB windows, 32 GiB), so the launcher picks by window count.
 struct Md5Lines : Md5 {
+  static constexpr int kStepBlocks = 2;
+};
+
+// SHA-256 likewise: 1.43 x the input size fetched at 16 KiB windows with 64-byte steps, the input size with
+// 128-byte steps, which are 1 % faster at 16 KiB and 5 % at 64 KiB windows (8 GiB batches) although the kernel
+// sits at the vector-issue ceiling either way.
+struct Sha256Lines : Sha256 {
   static constexpr int kStepBlocks = 2;
 };
 
@@ -579,6 +586,9 @@ __global__ __launch_bounds__(kSplitThreads) void sha256_split_jobs_kernel(const 
 // unset = by window count.
 const int g_md5_lines = getenv("OZCS_MD5_LINES") ? atoi(getenv("OZCS_MD5_LINES")) : -1;
 
+// Tuning override for experiments (read once): OZCS_SHA_LINES = 0 never, 1 always whole-line SHA-256 loader steps.
+const int g_sha_lines = getenv("OZCS_SHA_LINES") ? atoi(getenv("OZCS_SHA_LINES")) : -1;
+
 // Tuning override for experiments (read once): OZCS_SHA_SPLIT = 0 never, 1 always; unset = by window count.
 const int g_sha_split = getenv("OZCS_SHA_SPLIT") ? atoi(getenv("OZCS_SHA_SPLIT")) : -1;
 
@@ -606,8 +616,15 @@ hipError_t digest_launch(const DigestLaunch& p, int mode, int num_cus, hipStream
   if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
   const dim3 grid((unsigned)blocks), block(kLanes);
   if (p.algo == kAlgoSha256) {
-    if (mode == kModeCompute) digest_windows_kernel<Sha256, kModeCompute><<<grid, block, 0, stream>>>(p);
-    else digest_windows_kernel<Sha256, kModeVerify><<<grid, block, 0, stream>>>(p);
+    // as for MD5 below: whole-line loader steps once every SIMD has at least two wavefronts
+    const bool lines = g_sha_lines < 0 ? blocks >= (uint64_t)num_cus * 8 : g_sha_lines != 0;
+    if (lines) {
+      if (mode == kModeCompute) digest_windows_kernel<Sha256Lines, kModeCompute><<<grid, block, 0, stream>>>(p);
+      else digest_windows_kernel<Sha256Lines, kModeVerify><<<grid, block, 0, stream>>>(p);
+    } else {
+      if (mode == kModeCompute) digest_windows_kernel<Sha256, kModeCompute><<<grid, block, 0, stream>>>(p);
+      else digest_windows_kernel<Sha256, kModeVerify><<<grid, block, 0, stream>>>(p);
+    }
   } else {
     // at least two wavefronts for every SIMD (4 per CU): whole-line loader steps
     const bool lines = g_md5_lines < 0 ? blocks >= (uint64_t)num_cus * 8 : g_md5_lines != 0;

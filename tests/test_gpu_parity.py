@@ -579,8 +579,8 @@ def test_crc_wavefronts_starting_inside_their_windows(gpu, lanes):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("split", ["0", "1"])
-def test_sha256_one_and_two_wavefront_forms(gpu, split):
+@pytest.mark.parametrize("split,lines", [("0", "0"), ("0", "1"), ("1", "1")])
+def test_sha256_one_and_two_wavefront_forms(gpu, split, lines):
     # the launcher picks the form by window count; both must be right on any shape (MD5 rides along)
     import os
     import subprocess
@@ -588,7 +588,8 @@ def test_sha256_one_and_two_wavefront_forms(gpu, split):
     from conftest import ROOT
     e = dict(os.environ)
     e["OZCS_SHA_SPLIT"] = split
-    e["OZCS_MD5_LINES"] = split   # MD5's two loader forms (64-byte / whole-line steps) ride along
+    e["OZCS_MD5_LINES"] = lines   # the two loader forms (64-byte / whole-line steps) of MD5 and of one-wavefront SHA-256
+    e["OZCS_SHA_LINES"] = lines
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "variant_check.py"), "11", "digests"], env=e,
                        capture_output=True, text=True, timeout=170)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
