@@ -3,7 +3,9 @@
 # scripts/final_measure_r02.sh ran on the GPU box).
 set -eu
 for f in r02_configs.log r02_crc_window_sizes.log r02_pipeline_end_to_end.log r02_host_sync_calls.log r02_call_latency.log \
-         r02_small_chunk_batches.log r02_bench_default.json; do cp gpurun_out/$f profiles/$f; done
+         r02_small_chunk_batches.log r02_bench_default.json; do
+  if [ -f gpurun_out/$f ]; then cp gpurun_out/$f profiles/$f; fi   # the bench line is taken last, after a first collect
+done
 MIB=1048576
 H=$((64*256*MIB)); 
 python scripts/summarize_pmc.py headline CRC32-1048576-64 crc_windows_kernel $((H + 64*256*4)) 10

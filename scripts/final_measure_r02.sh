@@ -17,5 +17,7 @@ TAG=sha16k bash scripts/profile_r02.sh --type SHA256 --bpc 16384 --blocks 32 --s
 TAG=md516k bash scripts/profile_r02.sh --type MD5 --bpc 16384 --blocks 32 --steps 3 --warmup 1 > $O/prof_md516k.log 2>&1 || exit 1
 TAG=flat512 bash scripts/profile_r02.sh --type CRC32 --bpc 512 --steps 8 --warmup 2 > $O/prof_flat512.log 2>&1 || exit 1
 TAG=flat16k bash scripts/profile_r02.sh --type CRC32 --bpc 16384 --steps 8 --warmup 2 > $O/prof_flat16k.log 2>&1 || exit 1
+# the PMC record of these very sources first, so that the default bench line can carry the measured traffic
+bash scripts/collect_r02.sh > $O/collect.log 2>&1 || exit 1
 timeout -k 10 200 python -u bench.py > $O/r02_bench_default.json 2>/dev/null || exit 1
 echo final measure done
