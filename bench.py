@@ -178,6 +178,7 @@ def main():
     ap.add_argument("--bpc", type=int, default=MIB)
     ap.add_argument("--mode", default="compute", choices=["compute", "verify"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--zeros", action="store_true", help="all-zero data instead of random bytes (the rate must not depend on the data)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --device-index 0 rehearses the multi-rank path on a one-GPU box")
     ap.add_argument("--device-index", type=int, default=-1, help="GPU of this rank (default: LOCAL_RANK)")
@@ -217,9 +218,9 @@ def main():
     nbytes = (hi - lo) * BLOCK_BYTES
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + lo)
-    data = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    data = torch.zeros(nbytes, dtype=torch.uint8, device=dev) if args.zeros else torch.empty(nbytes, dtype=torch.uint8, device=dev)
     step_fill = 1 << 30
-    for o in range(0, nbytes, step_fill):
+    for o in range(0, 0 if args.zeros else nbytes, step_fill):
         n = min(step_fill, nbytes - o)
         data[o:o + n].view(torch.int64).random_(generator=gen)
     n_chunks = nbytes // CHUNK_BYTES
@@ -282,7 +283,7 @@ def main():
                 args.type, "1MB" if args.bpc == MIB else str(args.bpc)),
             "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic (all zeros)" if args.zeros else "synthetic",
             "config": {"workload": workload, "blocks_per_gpu": args.blocks, "chunk_bytes": CHUNK_BYTES,
                        "bytes_per_checksum": args.bpc, "windows_per_gpu": n_windows, "sharding": "by block, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
