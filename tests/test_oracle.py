@@ -120,3 +120,15 @@ def test_clmul_baseline_engine_equals_the_oracle(vectors):
         for t in (oracle.CRC32, oracle.CRC32C):
             bpc = int(rng.choice([64, 100, 4096, 1 << 20]))
             assert oracle.compute_clmul(t, bpc, d) == oracle.compute(t, bpc, d), (t, bpc, n, off)
+
+
+def test_gf2_arithmetic_of_the_kernels_against_the_bit_serial_definition():
+    """csrc/gf2_crc.h on the CPU (tests/cpp/test_gf2.cpp): check values, operator algebra, the operator bases behind
+    the LDS tables, and the merge identities the kernels rely on (pieces summed independently, initial register
+    folded into the first bytes, a window entered in the middle and wrapped round)."""
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(here, "cpp"), "gf2_test"])
+    r = subprocess.run([os.path.join(here, "cpp", "gf2_test")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "all passed" in r.stdout, r.stdout + r.stderr
