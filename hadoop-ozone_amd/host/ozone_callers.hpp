@@ -265,6 +265,17 @@ class PinnedChunkPool {
   std::vector<std::string> outs_;  // per slot: where the pipe delivers the digests of the slot's current ticket
 };
 
+// The ChunkInfo ContainerProtocolCalls.writeSmallFile builds for a small file that travels in one PutSmallFile
+// request (hadoop-hdds/common/src/main/java/org/apache/hadoop/hdds/scm/storage/ContainerProtocolCalls.java:334-345):
+// name "<localID>_chunk", offset 0, the whole length, the metadata pair OverWriteRequested=true, and CRC32 checksums
+// over 256-byte windows whatever the client configuration says.
+inline ChunkInfo writeSmallFileChunkInfo(long long localID, const void* data, size_t len) {
+  ChunkInfo info(std::to_string(localID) + "_chunk", 0, (long long)len);
+  info.addMetadata("OverWriteRequested", "true");
+  info.setChecksumData(Checksum(ChecksumType::CRC32, 256).computeChecksum(data, len));
+  return info;
+}
+
 // BlockOutputStream's data path around the checksum call
 // (hadoop-hdds/client/src/main/java/org/apache/hadoop/hdds/scm/storage/BlockOutputStream.java):
 //   write / writeChunkIfNeeded   :225-266   bytes go into the current chunk buffer; a full buffer becomes a chunk

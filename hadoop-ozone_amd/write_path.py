@@ -15,7 +15,18 @@ ChunkInfo records and the bytes -- is what the reference would ship.
 import ctypes
 
 from . import native
-from .checksum import ChecksumData, ChecksumType, ChunkInfo, OzoneChecksumException, OzoneClientConfig
+from .checksum import Checksum, ChecksumData, ChecksumType, ChunkInfo, OzoneChecksumException, OzoneClientConfig
+
+
+def writeSmallFileChunkInfo(localID, data):
+    """The ChunkInfo ContainerProtocolCalls.writeSmallFile builds for a small file that travels in one
+    PutSmallFile request (hadoop-hdds/common/src/main/java/org/apache/hadoop/hdds/scm/storage/
+    ContainerProtocolCalls.java:334-345): name "<localID>_chunk", offset 0, the whole length, the metadata pair
+    OverWriteRequested=true, and CRC32 checksums over 256-byte windows whatever the client configuration says."""
+    info = ChunkInfo("%d_chunk" % localID, 0, len(data))
+    info.addMetadata("OverWriteRequested", "true")
+    info.setChecksumData(Checksum(ChecksumType.CRC32, 256).computeChecksum(data))
+    return info
 
 
 class BlockOutputStream:

@@ -403,6 +403,17 @@ int main() {
     }
     EXPECT(joined == payload);
   }
+  // writeSmallFile's ChunkInfo (ContainerProtocolCalls.java:334-345): CRC32 at 256-byte windows, fixed
+  for (size_t n : {1u, 256u, 257u, 70000u}) {
+    std::string bytes(n, '\0');
+    oracle_fill_splitmix64(40 + n, (uint8_t*)&bytes[0], n);
+    const ChunkInfo info = writeSmallFileChunkInfo(91, bytes.data(), n);
+    EXPECT(info.getChunkName() == "91_chunk" && info.getOffset() == 0 && info.getLen() == (long long)n);
+    EXPECT(info.getMetadata().size() == 1 && info.getMetadata().at("OverWriteRequested") == "true");
+    EXPECT(info.getChecksumData().getBytesPerChecksum() == 256);
+    EXPECT(info.getChecksumData().getChecksums() == oracle_sums(ChecksumType::CRC32, 256, bytes));
+    EXPECT(ChunkInfo::getFromProtoBuf(info.getProtoBufMessage()).getChecksumData() == info.getChecksumData());
+  }
   std::printf(failures ? "%d FAILURES\n" : "host mirror: all passed\n", failures);
   ozcs_shutdown();
   return failures ? 1 : 0;
