@@ -163,6 +163,51 @@ struct ScrubChunk {
   std::string chunkFile;
 };
 
+namespace detail {
+
+// All chunks (each with the id of its block) read and hashed by ONE ozcs_verify_batch call; then the reference's
+// order of events replayed chunk by chunk.
+inline long long verifyChunks(const std::vector<std::pair<std::string, const ScrubChunk*>>& flat, ChunkLayOutVersion layout,
+                              const std::function<void(long long)>& throttler) {
+  std::vector<std::string> reads, stored;
+  std::vector<ozcs_vchunk> v(flat.size());
+  for (const auto& bc : flat) {
+    const ScrubChunk& c = *bc.second;
+    reads.push_back(readChunkWindows(c.chunkOffset, c.chunkLen, c.checksumData, c.chunkFile, layout));
+    const long long bpc = c.checksumData.getBytesPerChecksum();
+    const long long nwin = bpc ? ((long long)reads.back().size() + bpc - 1) / bpc : 0;
+    std::string s;
+    for (long long i = 0; i < nwin; i++) s += c.checksumData.getChecksums()[(size_t)i];
+    stored.push_back(std::move(s));
+  }
+  for (size_t i = 0; i < flat.size(); i++) {
+    const ScrubChunk& c = *flat[i].second;
+    const long long bpc = c.checksumData.getBytesPerChecksum();
+    const uint64_t nwin = bpc ? (reads[i].size() + (size_t)bpc - 1) / (size_t)bpc : 0;
+    v[i] = ozcs_vchunk{};
+    v[i].type = nwin ? (int)c.checksumData.getChecksumType() : OZCS_NONE;  // nothing read: only the length check applies
+    v[i].bpc = (uint32_t)bpc;
+    v[i].data = reads[i].empty() ? nullptr : reads[i].data();
+    v[i].len = reads[i].size();
+    v[i].expected = stored[i].data();
+    v[i].n_expected = nwin;
+  }
+  const int rc = flat.empty() ? OZCS_OK : ozcs_verify_batch(v.data(), (uint32_t)v.size());
+  long long total = 0;
+  for (size_t i = 0; i < flat.size(); i++) {
+    const ScrubChunk& c = *flat[i].second;
+    if (v[i].status != OZCS_OK) {
+      if (rc == OZCS_ENODEV || rc == OZCS_EHIP || rc == OZCS_ENOMEM)
+        throw GpuUnavailable(v[i].status, std::string("ozcs_verify_batch: ") + ozcs_last_error());
+      throw OzoneChecksumException("verify failed for chunk " + c.chunkName + ": status " + std::to_string(v[i].status));
+    }
+    total += replayChunk(flat[i].first, c.chunkName, c.chunkOffset, c.chunkLen, c.checksumData, reads[i], v[i].first_mismatch, throttler);
+  }
+  return total;
+}
+
+}  // namespace detail
+
 // The `for chunk in block.getChunks()` loop of KeyValueContainerCheck.scanData (:235-257) with ONE ozcs_verify_batch
 // call for all chunks instead of one checksum call per window.  All chunks are read and hashed in bulk first; then
 // the reference's order of events is replayed chunk by chunk, window by window, so the throttler sees exactly the
@@ -170,38 +215,35 @@ struct ScrubChunk {
 // verifyChunkFile raises for it.  Returns the number of bytes read.
 inline long long verifyBlock(const std::string& blockId, const std::vector<ScrubChunk>& chunks, ChunkLayOutVersion layout,
                              const std::function<void(long long)>& throttler = {}) {
-  std::vector<std::string> reads, stored;
-  std::vector<ozcs_vchunk> v(chunks.size());
-  for (const ScrubChunk& c : chunks) {
-    reads.push_back(detail::readChunkWindows(c.chunkOffset, c.chunkLen, c.checksumData, c.chunkFile, layout));
-    const long long bpc = c.checksumData.getBytesPerChecksum();
-    const long long nwin = bpc ? ((long long)reads.back().size() + bpc - 1) / bpc : 0;
-    std::string s;
-    for (long long i = 0; i < nwin; i++) s += c.checksumData.getChecksums()[(size_t)i];
-    stored.push_back(std::move(s));
-  }
-  for (size_t i = 0; i < chunks.size(); i++) {
-    const long long bpc = chunks[i].checksumData.getBytesPerChecksum();
-    const uint64_t nwin = bpc ? (reads[i].size() + (size_t)bpc - 1) / (size_t)bpc : 0;
-    v[i] = ozcs_vchunk{};
-    v[i].type = nwin ? (int)chunks[i].checksumData.getChecksumType() : OZCS_NONE;  // nothing read: only the length check applies
-    v[i].bpc = (uint32_t)bpc;
-    v[i].data = reads[i].empty() ? nullptr : reads[i].data();
-    v[i].len = reads[i].size();
-    v[i].expected = stored[i].data();
-    v[i].n_expected = nwin;
-  }
-  const int rc = chunks.empty() ? OZCS_OK : ozcs_verify_batch(v.data(), (uint32_t)v.size());
-  long long total = 0;
-  for (size_t i = 0; i < chunks.size(); i++) {
-    if (v[i].status != OZCS_OK) {
-      if (rc == OZCS_ENODEV || rc == OZCS_EHIP || rc == OZCS_ENOMEM)
-        throw GpuUnavailable(v[i].status, std::string("ozcs_verify_batch: ") + ozcs_last_error());
-      throw OzoneChecksumException("verify failed for chunk " + chunks[i].chunkName + ": status " + std::to_string(v[i].status));
+  std::vector<std::pair<std::string, const ScrubChunk*>> flat;
+  for (const ScrubChunk& c : chunks) flat.emplace_back(blockId, &c);
+  return detail::verifyChunks(flat, layout, throttler);
+}
+
+// The data scan of one container, scanData (:226-257): every chunk of every block, in order.  Chunks are gathered
+// across block boundaries into batches of about batchBytes of stored length, each batch one ozcs_verify_batch call;
+// the first failing chunk of the first failing block raises what verifyChunkFile raises for it and nothing behind it
+// is throttled (reads run ahead by at most one batch).
+struct ScrubBlock {
+  std::string blockId;
+  std::vector<ScrubChunk> chunks;
+};
+inline long long verifyContainer(const std::vector<ScrubBlock>& blocks, ChunkLayOutVersion layout,
+                                 const std::function<void(long long)>& throttler = {}, long long batchBytes = 1ll << 30) {
+  long long total = 0, size = 0;
+  std::vector<std::pair<std::string, const ScrubChunk*>> flat;
+  for (const ScrubBlock& b : blocks) {
+    for (const ScrubChunk& c : b.chunks) {
+      flat.emplace_back(b.blockId, &c);
+      size += c.chunkLen;
     }
-    total += detail::replayChunk(blockId, chunks[i].chunkName, chunks[i].chunkOffset, chunks[i].chunkLen, chunks[i].checksumData,
-                                 reads[i], v[i].first_mismatch, throttler);
+    if (size >= batchBytes) {
+      total += detail::verifyChunks(flat, layout, throttler);
+      flat.clear();
+      size = 0;
+    }
   }
+  if (!flat.empty()) total += detail::verifyChunks(flat, layout, throttler);
   return total;
 }
 

@@ -105,26 +105,20 @@ def verifyChunkProto(block_id, chunk_proto, chunk_file, layout, throttler=None, 
                           chunk_file, layout, throttler, canceler)
 
 
-def verifyBlock(block_id, chunks, layout, throttler=None, canceler=None):
-    """The `for chunk in block.getChunks()` loop of KeyValueContainerCheck.scanData (:235-257) with ONE
-    ozcs_verify_batch call for all chunks instead of one checksum call per window.
-
-    chunks: list of (chunk_name, chunk_offset, chunk_len, checksum_data, chunk_file).  All chunks are read and
-    hashed in bulk first; then the reference's order of events is replayed chunk by chunk, window by window
-    (throttle, judge, stop at the first failure): the throttler sees exactly the windows the reference would
-    have read up to the failure, and the first chunk (in order) that fails raises what verifyChecksum raises
-    for it.  Returns the number of bytes read."""
+def _verify_chunks(flat, layout, throttler, canceler):
+    """flat: list of (block_id, (chunk_name, chunk_offset, chunk_len, checksum_data, chunk_file)).  All chunks are
+    read and hashed by ONE ozcs_verify_batch call; then the reference's order of events is replayed chunk by chunk."""
     import ctypes
     import numpy as np
     reads = []
-    for name, off, ln, cd, path in chunks:
+    for bid, (name, off, ln, cd, path) in flat:
         data = _read_chunk(off, ln, cd, path, layout)
         bpc = cd.getBytesPerChecksum()
         nwin = (len(data) + bpc - 1) // bpc if bpc else 0
         reads.append((np.frombuffer(data, dtype=np.uint8), b"".join(cd.getChecksums()[:nwin]), nwin))
-    n = len(chunks)
+    n = len(flat)
     arr = (native.OzcsVChunk * max(1, n))()
-    for i, ((name, off, ln, cd, path), (data, stored, nwin)) in enumerate(zip(chunks, reads)):
+    for i, ((bid, (name, off, ln, cd, path)), (data, stored, nwin)) in enumerate(zip(flat, reads)):
         t = cd.getChecksumType()
         arr[i].type = int(t) if nwin else int(ChecksumType.NONE)   # nothing read: only the length check applies
         arr[i].bpc = cd.getBytesPerChecksum()
@@ -135,10 +129,50 @@ def verifyBlock(block_id, chunks, layout, throttler=None, canceler=None):
         arr[i].start_index = 0
     rc = native.lib().ozcs_verify_batch(arr, n) if n else native.OK
     total = 0
-    for i, ((name, off, ln, cd, path), (data, stored, nwin)) in enumerate(zip(chunks, reads)):
+    for i, ((bid, (name, off, ln, cd, path)), (data, stored, nwin)) in enumerate(zip(flat, reads)):
         if arr[i].status != native.OK:
             if rc in (native.ENODEV, native.EHIP, native.ENOMEM):
                 native.check(arr[i].status)
             raise OzoneChecksumException("verify failed for chunk %s: status %d" % (name, arr[i].status))
-        total += _replay(block_id, name, off, ln, cd, data, arr[i].first_mismatch, throttler, canceler)
+        total += _replay(bid, name, off, ln, cd, data, arr[i].first_mismatch, throttler, canceler)
+    return total
+
+
+def verifyBlock(block_id, chunks, layout, throttler=None, canceler=None):
+    """The `for chunk in block.getChunks()` loop of KeyValueContainerCheck.scanData (:235-257) with ONE
+    ozcs_verify_batch call for all chunks instead of one checksum call per window.
+
+    chunks: list of (chunk_name, chunk_offset, chunk_len, checksum_data, chunk_file).  All chunks are read and
+    hashed in bulk first; then the reference's order of events is replayed chunk by chunk, window by window
+    (throttle, judge, stop at the first failure): the throttler sees exactly the windows the reference would
+    have read up to the failure, and the first chunk (in order) that fails raises what verifyChecksum raises
+    for it.  Returns the number of bytes read."""
+    return _verify_chunks([(block_id, c) for c in chunks], layout, throttler, canceler)
+
+
+def verifyContainer(blocks, layout, throttler=None, canceler=None, batch_bytes=1 << 30):
+    """The data scan of one container, KeyValueContainerCheck.scanData (:226-257): every chunk of every block, in
+    order.  Chunks are gathered across block boundaries into batches of about `batch_bytes` of stored length, each
+    batch one ozcs_verify_batch call; the reference's order of events is then replayed chunk by chunk, so the first
+    failing chunk of the first failing block raises what verifyChecksum raises for it and nothing behind it is
+    throttled.  (A chunk behind a failure may already have been read: reads run ahead by at most one batch.)
+
+    blocks: list of (block_id, chunks) with chunks as in verifyBlock.  Returns the number of bytes read."""
+    total = 0
+    batch, size = [], 0
+
+    def run():
+        nonlocal total, batch, size
+        # one call for the whole batch; replay needs every chunk's block id
+        flat = [(bid, c) for bid, chunks in batch for c in chunks]
+        total += _verify_chunks(flat, layout, throttler, canceler)
+        batch, size = [], 0
+
+    for bid, chunks in blocks:
+        batch.append((bid, chunks))
+        size += sum(c[2] for c in chunks)
+        if size >= batch_bytes:
+            run()
+    if batch:
+        run()
     return total

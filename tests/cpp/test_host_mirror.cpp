@@ -273,6 +273,20 @@ int main() {
       EXPECT(w.find("Inconsistent read for chunk=ChunkInfo{chunkName='c1, offset=40960, len=40960} checksum item 3 expected checksum [") == 0);
       EXPECT(seen.size() == 10 + 4);   // chunk 0's ten windows, chunk 1's windows 0..3
     }
+    // the same chunks as a container of three one-chunk blocks, batches cut after every block
+    std::vector<ScrubBlock> blocks;
+    for (int i = 0; i < 3; i++) blocks.push_back(ScrubBlock{"blk#" + std::to_string(i), {chunks[(size_t)i]}});
+    seen.clear();
+    try {
+      verifyContainer(blocks, ChunkLayOutVersion::FILE_PER_BLOCK, [&](long long n) { seen.push_back(n); }, chunkLen);
+      EXPECT(!"corrupt container accepted");
+    } catch (const OzoneChecksumException& e) {
+      const std::string w = e.what();
+      EXPECT(w.find(" for block blk#1") == w.size() - 16);
+      EXPECT(seen.size() == 10 + 4);
+    }
+    put(file);
+    EXPECT(verifyContainer(blocks, ChunkLayOutVersion::FILE_PER_BLOCK) == 3 * chunkLen);
     std::remove(path.c_str());
   }
 

@@ -349,3 +349,32 @@ def test_write_small_file_chunk_info():
         assert (cd.getChecksumType(), cd.getBytesPerChecksum()) == (ChecksumType.CRC32, 256)
         assert b"".join(cd.getChecksums()) == oracle.compute(oracle.CRC32, 256, data)
         assert ChunkInfo.getFromProtoBuf(info.getProtoBufMessage()).getChecksumData() == cd
+
+
+@pytest.mark.gpu
+def test_scrubber_whole_container_in_batches(tmp_path):
+    # scanData over a container of 5 block files x 6 chunks; batches cut across block boundaries (here: every
+    # ~2.5 blocks); the first failing chunk of the first failing block is what is reported
+    chunk_len, bpc = 48 * 1024, 16384
+    blocks = []
+    for b in range(5):
+        datas = [oracle.splitmix64(1000 + 10 * b + i, chunk_len).tobytes() for i in range(6)]
+        path = tmp_path / ("%d.block" % b)
+        path.write_bytes(b"".join(datas))
+        chunks = [("b%dc%d" % (b, i), i * chunk_len, chunk_len,
+                   ChecksumData(ChecksumType.CRC32C, bpc, [oracle.compute(oracle.CRC32C, bpc, d[o:o + bpc]) for o in range(0, chunk_len, bpc)]),
+                   str(path)) for i, d in enumerate(datas)]
+        blocks.append(("blk%d" % b, chunks))
+    seen = []
+    total = scrubber.verifyContainer(blocks, scrubber.FILE_PER_BLOCK, throttler=lambda n, c: seen.append(n),
+                                     batch_bytes=15 * chunk_len)
+    assert total == 30 * chunk_len and sum(seen) == total and len(seen) == 30 * 3
+    for b, (ci, w) in ((3, (4, 1)), (1, (2, 2))):   # corrupt block 3 first, then also block 1: block 1 is reported
+        p = tmp_path / ("%d.block" % b)
+        raw = bytearray(p.read_bytes())
+        raw[ci * chunk_len + w * bpc + 5] ^= 0x10
+        p.write_bytes(bytes(raw))
+    seen.clear()
+    with pytest.raises(OzoneChecksumException, match=r"chunkName='b1c2, offset=98304, len=49152\} checksum item 2 expected .* for block blk1"):
+        scrubber.verifyContainer(blocks, scrubber.FILE_PER_BLOCK, throttler=lambda n, c: seen.append(n), batch_bytes=15 * chunk_len)
+    assert len(seen) == (6 + 2) * 3 + 3   # block 0 whole, block 1 chunks 0-1 whole, chunk 2 up to its failing window
