@@ -58,6 +58,26 @@ public final class GpuChecksum {
       ByteBuffer sums, int sumsPosition, int sumsLimit, ByteBuffer data, int dataPosition, int dataLimit);
 
   /**
+   * One digest per buffer of the list, each over at most bytesPerSum bytes from its position, empty buffers skipped
+   * (what ChunkBufferImplWithByteBufferList.iterate is meant to hand to the per-window function): the
+   * computeChecksum(List&lt;ByteString&gt;) case in one native call.  Direct buffers; no position moves.  Returns the
+   * digest count or a negative OZCS_E* code.
+   */
+  public static long calculateWindowSums(int bytesPerSum, int checksumType, ByteBuffer sums, ByteBuffer[] windows) {
+    final int[] positions = new int[windows.length];
+    final int[] limits = new int[windows.length];
+    for (int i = 0; i < windows.length; i++) {
+      positions[i] = windows[i].position();
+      limits[i] = windows[i].limit();
+    }
+    return calculateWindowSumsDirect(bytesPerSum, checksumType, sums, sums.position(), sums.limit(), windows,
+        positions, limits);
+  }
+
+  private static native long calculateWindowSumsDirect(int bytesPerSum, int checksumType,
+      ByteBuffer sums, int sumsPosition, int sumsLimit, ByteBuffer[] windows, int[] positions, int[] limits);
+
+  /**
    * ozcs_verify: returns -1 when every window matches, the first mismatching index (relative to the
    * computed list) otherwise, or a code below -1 ( -1 + OZCS_E* ) when the library could not run.
    * Shape of NativeCRC32Wrapper.verifyChunkedSumsByteArray.

@@ -97,6 +97,59 @@ JNIEXPORT jlong JNICALL JFN(calculateChunkedSumsDirect)(JNIEnv* env, jclass cls,
   return rc == OZCS_OK ? (jlong)n : (jlong)rc;
 }
 
+/* One window per direct buffer, each cut to bytesPerSum bytes (Checksum.java:186-198) and empty ones skipped, as
+ * ChunkBufferImplWithByteBufferList.iterate hands them out: the List<ByteString> / list-backed ChunkBuffer case in
+ * ONE ozcs_compute_batch call.  Digests go to sums[sumsPos ...] back to back; returns their count. */
+JNIEXPORT jlong JNICALL JFN(calculateWindowSumsDirect)(JNIEnv* env, jclass cls, jint bpc, jint type,
+    jobject sums, jint sumsPos, jint sumsLimit, jobjectArray windows, jintArray positions, jintArray limits) {
+  (void)cls;
+  uint8_t* s = (uint8_t*)(*env)->GetDirectBufferAddress(env, sums);
+  const jsize n = (*env)->GetArrayLength(env, windows);
+  if (!s || bpc <= 0 || sumsPos < 0 || sumsLimit < sumsPos || sumsLimit > (*env)->GetDirectBufferCapacity(env, sums)) return OZCS_EINVAL;
+  if ((*env)->GetArrayLength(env, positions) < n || (*env)->GetArrayLength(env, limits) < n) return OZCS_EINVAL;
+  const size_t ds = ozcs_digest_size(type);
+  if (type == OZCS_NONE || n == 0) return 0;
+  if (!ds) return OZCS_EINVAL;
+  ozcs_chunk* jobs = (ozcs_chunk*)calloc((size_t)n, sizeof(ozcs_chunk));
+  jint* pl = (jint*)malloc(2 * (size_t)n * sizeof(jint));
+  if (!jobs || !pl) {
+    free(jobs);
+    free(pl);
+    return OZCS_ENOMEM;
+  }
+  (*env)->GetIntArrayRegion(env, positions, 0, n, pl);
+  (*env)->GetIntArrayRegion(env, limits, 0, n, pl + n);
+  jlong result = 0;
+  uint32_t k = 0;
+  for (jsize i = 0; i < n && result == 0; i++) {
+    jobject w = (*env)->GetObjectArrayElement(env, windows, i);
+    uint8_t* d = w ? (uint8_t*)(*env)->GetDirectBufferAddress(env, w) : NULL;
+    const jint pos = pl[i], lim = pl[n + i];
+    if (!d || pos < 0 || lim < pos || lim > (*env)->GetDirectBufferCapacity(env, w)) {
+      result = OZCS_EINVAL;
+    } else if (lim > pos) {
+      if ((jlong)sumsPos + (jlong)((k + 1) * ds) > sumsLimit) {
+        result = OZCS_EINVAL;
+        break;
+      }
+      jobs[k].data = d + pos;
+      jobs[k].len = (uint64_t)(lim - pos < bpc ? lim - pos : bpc);
+      jobs[k].sums = s + sumsPos + (size_t)k * ds;
+      jobs[k].sums_cap = ds;
+      jobs[k].bpc = (uint32_t)bpc;
+      jobs[k].type = type;
+      k++;
+    }
+  }
+  if (result == 0 && k) {
+    const int rc = ozcs_compute_batch(jobs, k);
+    result = rc == OZCS_OK ? (jlong)k : (jlong)rc;
+  }
+  free(jobs);
+  free(pl);
+  return result;
+}
+
 JNIEXPORT jlong JNICALL JFN(verifyChunkedSumsByteArray)(JNIEnv* env, jclass cls, jint bpc, jint type,
     jbyteArray sums, jint sumsOff, jint numSums, jint startIndex, jbyteArray data, jint dataOff, jint dataLen) {
   (void)cls;

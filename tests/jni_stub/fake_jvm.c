@@ -10,7 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-enum { kByteArray = 1, kIntArray = 2, kDirectBuffer = 3 };
+enum { kByteArray = 1, kIntArray = 2, kDirectBuffer = 3, kObjectArray = 4 };
 struct _jobject {
   int kind;
   void* ptr;
@@ -50,9 +50,23 @@ static jobject NewDirectByteBuffer(JNIEnv* env, void* address, jlong capacity) {
 static void* GetDirectBufferAddress(JNIEnv* env, jobject b) { (void)env; return b && b->kind == kDirectBuffer ? b->ptr : NULL; }
 static jlong GetDirectBufferCapacity(JNIEnv* env, jobject b) { (void)env; return b && b->kind == kDirectBuffer ? b->len : -1; }
 
+static jobject GetObjectArrayElement(JNIEnv* env, jobjectArray a, jsize index) {
+  (void)env;
+  if (!a || a->kind != kObjectArray || index < 0 || index >= a->len) {
+    t_pending = 1;
+    return NULL;
+  }
+  return ((jobject*)a->ptr)[index];
+}
+static void GetIntArrayRegion(JNIEnv* env, jintArray a, jsize start, jsize len, jint* buf) {
+  (void)env;
+  if (region_ok(a, kIntArray, start, len)) memcpy(buf, (jint*)a->ptr + start, (size_t)len * sizeof(jint));
+}
+
 static const struct JNINativeInterface_ g_table = {
     GetArrayLength, GetByteArrayRegion, SetByteArrayRegion, SetIntArrayRegion,
     ExceptionCheck, NewDirectByteBuffer, GetDirectBufferAddress, GetDirectBufferCapacity,
+    GetObjectArrayElement, GetIntArrayRegion,
 };
 static JNIEnv g_env = &g_table;
 

@@ -25,6 +25,7 @@ typedef jobject jclass;
 typedef jobject jarray;
 typedef jarray jbyteArray;
 typedef jarray jintArray;
+typedef jarray jobjectArray;
 
 struct JNINativeInterface_;
 typedef const struct JNINativeInterface_* JNIEnv;
@@ -37,5 +38,7 @@ struct JNINativeInterface_ {
   jobject (*NewDirectByteBuffer)(JNIEnv* env, void* address, jlong capacity);
   void* (*GetDirectBufferAddress)(JNIEnv* env, jobject buf);
   jlong (*GetDirectBufferCapacity)(JNIEnv* env, jobject buf);
+  jobject (*GetObjectArrayElement)(JNIEnv* env, jobjectArray array, jsize index);
+  void (*GetIntArrayRegion)(JNIEnv* env, jintArray array, jsize start, jsize len, jint* buf);
 };
 #endif

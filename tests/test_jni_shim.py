@@ -11,7 +11,7 @@ SHIM = os.path.join(ROOT, "hadoop-ozone_amd", "jni", "ozcs_jni.c")
 JAVA = os.path.join(ROOT, "hadoop-ozone_amd", "jni", "GpuChecksum.java")
 
 JAVA_TO_JNI = {"int": "jint", "long": "jlong", "boolean": "jboolean", "byte[]": "jbyteArray", "int[]": "jintArray",
-               "ByteBuffer": "jobject", "void": "void"}
+               "ByteBuffer": "jobject", "ByteBuffer[]": "jobjectArray", "void": "void"}
 
 
 def test_shim_is_valid_c_against_the_abi_header():
@@ -53,7 +53,7 @@ import numpy as np  # noqa: E402
 import pytest  # noqa: E402
 
 FAKE = os.path.join(ROOT, "tests", "jni_stub", "libozcs_jni_fake.so")
-K_BYTES, K_INTS, K_DIRECT = 1, 2, 3
+K_BYTES, K_INTS, K_DIRECT, K_OBJECTS = 1, 2, 3, 4
 PFX = "Java_org_apache_hadoop_ozone_common_GpuChecksum_"
 
 
@@ -81,6 +81,7 @@ class FakeJvm:
                "calculateChunkedSumsDirect": (J, [I, I, V, I, I, V, I, I]),
                "verifyChunkedSumsByteArray": (J, [I, I, V, I, I, I, V, I, I]),
                "verifyChunkedSumsDirect": (J, [I, I, V, I, I, I, I, V, I, I]),
+               "calculateWindowSumsDirect": (J, [I, I, V, I, I, V, V, V]),
                "pipeCreate": (J, [I, I, J]), "pipeDestroy": (None, [J]), "pipeAcquire": (V, [J, V]),
                "pipeSubmit": (I, [J, I, I, I, J, V]), "pipeWait": (J, [J, I]),
                "pipeNextCompleted": (J, [J, B, V]), "pipeTicketSlot": (I, [I])}
@@ -203,3 +204,28 @@ def test_shim_pipe_wrappers(jvm):
             assert bytes(out[:len(want)]) == want
     finally:
         jvm.pipeDestroy(pipe)
+
+
+@pytest.mark.gpu
+def test_shim_one_window_per_buffer_in_one_call(jvm):
+    # the List<ByteString> case: one digest per direct buffer, each cut to bytesPerSum, empty buffers skipped
+    import oracle
+    bpc = 4096
+    lens = [4096, 4096, 0, 100, 9000, 4096, 1]
+    bufs = [oracle.splitmix64(500 + i, n + 16) for i, n in enumerate(lens)]        # 8 bytes of slack either side
+    objs = np.array([jvm.obj(K_DIRECT, b) for b in bufs], dtype=np.uint64)
+    pos = np.full(len(lens), 8, dtype=np.int32)
+    lim = np.array([8 + n for n in lens], dtype=np.int32)
+    for t, ds in ((oracle.CRC32C, 4), (oracle.MD5, 16)):
+        want = b"".join(oracle.compute(t, bpc, b[8:8 + min(n, bpc)]) for b, n in zip(bufs, lens) if n)
+        sums = np.full(len(want) + 12, 0xEE, dtype=np.uint8)
+        got = jvm.calculateWindowSumsDirect(bpc, t, jvm.obj(K_DIRECT, sums), 4, sums.size, jvm.obj(K_OBJECTS, objs),
+                                            jvm.obj(K_INTS, pos), jvm.obj(K_INTS, lim))
+        assert got == len(want) // ds and bytes(sums[4:4 + len(want)]) == want and bytes(sums[4 + len(want):]) == b"\xee" * 8
+    short = np.zeros(8, dtype=np.uint8)   # room for two CRC digests only
+    assert jvm.calculateWindowSumsDirect(bpc, oracle.CRC32, jvm.obj(K_DIRECT, short), 0, 8, jvm.obj(K_OBJECTS, objs),
+                                         jvm.obj(K_INTS, pos), jvm.obj(K_INTS, lim)) == -1
+    lim[1] = bufs[1].size + 1             # a limit beyond its buffer's capacity
+    sums = np.zeros(64, dtype=np.uint8)
+    assert jvm.calculateWindowSumsDirect(bpc, oracle.CRC32, jvm.obj(K_DIRECT, sums), 0, 64, jvm.obj(K_OBJECTS, objs),
+                                         jvm.obj(K_INTS, pos), jvm.obj(K_INTS, lim)) == -1
