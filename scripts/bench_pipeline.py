@@ -97,6 +97,10 @@ def main():
                                       "harvest": "any completed ticket" if any_order else "oldest ticket first",
                                       "GBps": round(run(L, slots, n, False, False, bpc, any_order, only=t), 2)}), flush=True)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "mix-in-order":   # one stream that ships its chunks in order: CRC32:MD5 3:1 at 1 MiB windows
+        for slots in (128, 256, 512):
+            print(json.dumps({"slots": slots, "oldest_first_GBps": round(run(L, slots, 4096, True, False, MIB, False), 2)}), flush=True)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "mix":   # quick look: CRC32:MD5 3:1 at 1 MiB windows only
         for slots in (64, 128):
             print(json.dumps({"slots": slots, "any_order_GBps": round(run(L, slots, 4096, True, False, MIB, True), 2)}), flush=True)
