@@ -27,6 +27,11 @@
 // the per-device pointer resolved in ozcs_init (DeviceInfo::noalloc_verdicts), never the name.
 static __device__ __align__(256) unsigned long long scratch[OZCS_NOALLOC_MAX_CHUNKS];
 
+extern "C" {
+static int init_impl(uint32_t device_mask);
+static int verify_batch_impl(ozcs_vchunk* v, uint32_t n_chunks);
+}
+
 namespace ozcs {
 
 thread_local std::string t_err;
@@ -51,6 +56,51 @@ Global& global() {
 }
 
 std::atomic<uint64_t> s_calls{0}, s_bytes{0}, s_windows{0}, s_h2d{0}, s_d2h{0}, s_launches{0};
+std::atomic<uint64_t> s_errors{0}, s_unavailable{0};
+std::atomic<uint64_t> s_timed_calls{0}, s_timed_bytes{0}, s_h2d_us{0}, s_kernel_us{0}, s_d2h_us{0};
+
+int tally(int rc, bool empty_is_flow) {
+  if (rc >= 0 || rc == OZCS_EBUSY || (empty_is_flow && rc == OZCS_EEMPTY)) return rc;
+  s_errors.fetch_add(1, std::memory_order_relaxed);
+  if (rc == OZCS_ENODEV || rc == OZCS_EHIP || rc == OZCS_ENOMEM) s_unavailable.fetch_add(1, std::memory_order_relaxed);
+  return rc;
+}
+
+// ---- phase timing of the host-pointer calls, one call in OZCS_STATS_SAMPLE_EVERY per pooled context ----
+// Four events on the call's stream: before the copies in, after them, after the kernels, after the copy back.
+// The first call of a context is timed (so that a process that makes a handful of calls has figures at all),
+// then every OZCS_STATS_SAMPLE_EVERY-th.  Events are created on first use and live with the context.
+PhaseTimer::PhaseTimer(HostCtx* c, uint64_t bytes) : c_(c), bytes_(bytes), on_(false) {
+  if (c->calls++ % OZCS_STATS_SAMPLE_EVERY != 0) return;
+  for (hipEvent_t& ev : c->phase)
+    if (!ev && hipEventCreate(&ev) != hipSuccess) {
+      ev = nullptr;
+      (void)hipGetLastError();
+      return;
+    }
+  on_ = true;
+}
+void PhaseTimer::mark(int i) {
+  if (on_ && hipEventRecord(c_->phase[i], c_->stream) != hipSuccess) {
+    (void)hipGetLastError();
+    on_ = false;
+  }
+}
+// After the stream has been synchronised.
+void PhaseTimer::finish() {
+  if (!on_) return;
+  float ms[3] = {0, 0, 0};
+  for (int i = 0; i < 3; i++)
+    if (hipEventElapsedTime(&ms[i], c_->phase[i], c_->phase[i + 1]) != hipSuccess) {
+      (void)hipGetLastError();
+      return;
+    }
+  s_timed_calls.fetch_add(1, std::memory_order_relaxed);
+  s_timed_bytes.fetch_add(bytes_, std::memory_order_relaxed);
+  s_h2d_us.fetch_add((uint64_t)(ms[0] * 1000.0f + 0.5f), std::memory_order_relaxed);
+  s_kernel_us.fetch_add((uint64_t)(ms[1] * 1000.0f + 0.5f), std::memory_order_relaxed);
+  s_d2h_us.fetch_add((uint64_t)(ms[2] * 1000.0f + 0.5f), std::memory_order_relaxed);
+}
 
 // Keeps the calling thread's current device unchanged across a call.
 DeviceGuard::DeviceGuard(int dev) : prev_(-1), ok_(false) {
@@ -72,7 +122,7 @@ const DeviceInfo* find_device(int device) {
 int ensure_init() {
   Global& g = global();
   if (g.inited.load(std::memory_order_acquire)) return OZCS_OK;
-  return ozcs_init(0);
+  return init_impl(0);
 }
 
 // ---- scratch contexts for the host-pointer calls: pooled per device, grow-only buffers ----
@@ -111,6 +161,8 @@ static void destroy_ctx(HostCtx* c) {
   if (c->d_aux) (void)hipFree(c->d_aux);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->h_sums) (void)hipHostFree(c->h_sums);
+  for (hipEvent_t ev : c->phase)
+    if (ev) (void)hipEventDestroy(ev);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -277,20 +329,26 @@ static int compute_host_on(int device, int type, uint32_t bpc, const void* data,
   int rc = ctx_reserve(&c->d_data, &c->data_cap, len);
   if (rc == OZCS_OK) rc = ctx_reserve(&c->d_sums, &c->sums_cap, n * ds);
   hipError_t e = hipSuccess;
+  PhaseTimer timer(c, len);
+  timer.mark(0);
   if (rc == OZCS_OK) {
     e = hipMemcpyAsync(c->d_data, data, len, hipMemcpyHostToDevice, c->stream);
     if (e != hipSuccess) rc = fail_hip(e, "hipMemcpyAsync H2D");
   }
+  timer.mark(1);
   if (rc == OZCS_OK)
     rc = launch_windows(*dev, type, bpc, c->d_data, len, 1, len, kModeCompute, c->d_sums, nullptr, 0, 0, 0, nullptr,
                         c->stream);
+  timer.mark(2);
   if (rc == OZCS_OK) {
     e = hipMemcpyAsync(sums_out, c->d_sums, n * ds, hipMemcpyDeviceToHost, c->stream);
     if (e != hipSuccess) rc = fail_hip(e, "hipMemcpyAsync D2H");
   }
+  timer.mark(3);
   e = hipStreamSynchronize(c->stream);
   if (rc == OZCS_OK && e != hipSuccess) rc = fail_hip(e, "hipStreamSynchronize");
   if (rc == OZCS_OK) {
+    timer.finish();
     s_h2d.fetch_add(len, std::memory_order_relaxed);
     s_d2h.fetch_add(n * ds, std::memory_order_relaxed);
   }
@@ -384,6 +442,10 @@ static void batch_on_device(int device, ozcs_chunk* chunks, uint32_t lo, uint32_
       hipError_t e = hipSuccess;
       uint8_t* dd = static_cast<uint8_t*>(c->d_data);
       uint8_t* dsums = static_cast<uint8_t*>(c->d_sums);
+      // Phase times of a group: all copies in are queued before the first kernel of the group except the small
+      // descriptor and job lists, which are counted with the kernels they precede.
+      PhaseTimer timer(c, group_bytes);
+      timer.mark(0);
       if (rc == OZCS_OK && staged_bytes) {
         // ---- gather the staged chunks; each finished piece starts its copy while the next is gathered.
         // One thread's memcpy feeds about half of what the link takes, so large gathers are shared by up to
@@ -439,6 +501,11 @@ static void batch_on_device(int device, ozcs_chunk* chunks, uint32_t lo, uint32_
             if (x != hipSuccess && e == hipSuccess) e = x;
         }
       }
+      // the other chunks' bytes: a copy each (they are too large to be worth staging)
+      for (const Item& it : items)
+        if (!it.staged && rc == OZCS_OK && e == hipSuccess)
+          e = hipMemcpyAsync(dd + it.data_off, chunks[it.idx].data, chunks[it.idx].len, hipMemcpyHostToDevice, c->stream);
+      timer.mark(1);
       if (rc == OZCS_OK && n_desc) {
         // ---- descriptors of the small chunks' windows, grouped by checksum type ----
         WindowDesc* hd = reinterpret_cast<WindowDesc*>(static_cast<uint8_t*>(c->h_stage) + staged_bytes);  // 256-aligned
@@ -474,10 +541,7 @@ static void batch_on_device(int device, ozcs_chunk* chunks, uint32_t lo, uint32_
           s_bytes.fetch_add(bytes[t], std::memory_order_relaxed);
         }
       }
-      // ---- the other chunks: a copy each if not staged, digests through the job list, CRC one launch per chunk ----
-      for (const Item& it : items)
-        if (!it.staged && rc == OZCS_OK && e == hipSuccess)
-          e = hipMemcpyAsync(dd + it.data_off, chunks[it.idx].data, chunks[it.idx].len, hipMemcpyHostToDevice, c->stream);
+      // ---- the other chunks: digests through the job list, CRC one launch per chunk ----
       if (rc == OZCS_OK && e == hipSuccess && n_jobs) {
         // one job per chunk, grouped by algorithm; each group is one launch (more only where the windows of a
         // group pass what a launch can number)
@@ -520,6 +584,7 @@ static void batch_on_device(int device, ozcs_chunk* chunks, uint32_t lo, uint32_
           rc = launch_windows(*dev, ch.type, ch.bpc, dd + it.data_off, ch.len, 1, ch.len, kModeCompute,
                               dsums + it.sums_off, nullptr, 0, 0, 0, nullptr, c->stream);
       }
+      timer.mark(2);
       // ---- digests back: one copy into pinned memory and a scatter, or a copy per chunk ----
       if (rc == OZCS_OK && e == hipSuccess) {
         if (pinned_sums) {
@@ -530,9 +595,11 @@ static void batch_on_device(int device, ozcs_chunk* chunks, uint32_t lo, uint32_
               e = hipMemcpyAsync(chunks[it.idx].sums, dsums + it.sums_off, it.n * it.ds, hipMemcpyDeviceToHost, c->stream);
         }
       }
+      timer.mark(3);
       const hipError_t es = hipStreamSynchronize(c->stream);
       if (rc == OZCS_OK && e != hipSuccess) rc = fail_hip(e, "batch enqueue");
       if (rc == OZCS_OK && es != hipSuccess) rc = fail_hip(es, "hipStreamSynchronize");
+      if (rc == OZCS_OK) timer.finish();
       for (const Item& it : items) {
         ozcs_chunk& ch = chunks[it.idx];
         ch.status = rc;
@@ -617,7 +684,7 @@ void ozcs_shard_chunks(const ozcs_chunk* chunks, uint32_t n_chunks, uint32_t n_p
   cuts[n_parts] = n_chunks;
 }
 
-int ozcs_init(uint32_t device_mask) {
+static int init_impl(uint32_t device_mask) {
   Global& g = global();
   std::lock_guard<std::mutex> lk(g.init_mu);
   if (g.inited.load(std::memory_order_acquire)) return OZCS_OK;
@@ -645,13 +712,16 @@ int ozcs_init(uint32_t device_mask) {
     devs.push_back(d);
   }
   if (devs.empty()) return fail(OZCS_ENODEV, "no gfx950 device among %d HIP device(s)", n);
-  // Test hook (read at init): OZCS_TEST_REPLICATE_DEVICES = k lists every usable device k times, so that the
-  // multi-device code paths (sharding a batch over devices, one host thread per shard) run on a one-GPU machine.
+#ifdef OZCS_TEST_HOOKS
+  // Test builds only (libozcs_testhooks.so): OZCS_TEST_REPLICATE_DEVICES = k lists every usable device k times, so
+  // that the multi-device code paths (sharding a batch over devices, one host thread per shard) run on a one-GPU
+  // machine.  The product library does not read the variable.
   if (const char* rep = getenv("OZCS_TEST_REPLICATE_DEVICES")) {
     const int k = atoi(rep);
     const std::vector<DeviceInfo> once = devs;
     for (int r = 1; r < k && r < 8; r++) devs.insert(devs.end(), once.begin(), once.end());
   }
+#endif
   g.devs = devs;
   g.inited.store(true, std::memory_order_release);
   return OZCS_OK;
@@ -686,9 +756,16 @@ void ozcs_get_stats(ozcs_stats* out) {
   out->h2d_bytes = s_h2d.load();
   out->d2h_bytes = s_d2h.load();
   out->kernel_launches = s_launches.load();
+  out->errors = s_errors.load();
+  out->unavailable = s_unavailable.load();
+  out->timed_calls = s_timed_calls.load();
+  out->timed_bytes = s_timed_bytes.load();
+  out->h2d_us = s_h2d_us.load();
+  out->kernel_us = s_kernel_us.load();
+  out->d2h_us = s_d2h_us.load();
 }
 
-int ozcs_compute_device(int device, int type, uint32_t bpc, const void* d_data, uint64_t chunk_len,
+static int compute_device_impl(int device, int type, uint32_t bpc, const void* d_data, uint64_t chunk_len,
                         uint64_t n_chunks, uint64_t chunk_stride, void* d_sums, uint64_t sums_cap,
                         void* hip_stream) {
   int rc = check_type_bpc(type, bpc);
@@ -708,7 +785,7 @@ int ozcs_compute_device(int device, int type, uint32_t bpc, const void* d_data, 
                         0, 0, nullptr, static_cast<hipStream_t>(hip_stream));
 }
 
-int ozcs_verify_device(int device, int type, uint32_t bpc, const void* d_data, uint64_t chunk_len,
+static int verify_device_impl(int device, int type, uint32_t bpc, const void* d_data, uint64_t chunk_len,
                        uint64_t n_chunks, uint64_t chunk_stride, const void* d_expected,
                        uint64_t expected_stride, uint64_t n_expected, uint64_t start_index,
                        int64_t* d_first_mismatch, void* hip_stream) {
@@ -733,7 +810,7 @@ int ozcs_verify_device(int device, int type, uint32_t bpc, const void* d_data, u
                         reinterpret_cast<unsigned long long*>(d_first_mismatch), stream);
 }
 
-int ozcs_verify_device_noalloc(int device, int type, uint32_t bpc, const void* d_data, uint64_t chunk_len,
+static int verify_device_noalloc_impl(int device, int type, uint32_t bpc, const void* d_data, uint64_t chunk_len,
                                uint64_t n_chunks, uint64_t chunk_stride, const void* d_expected,
                                uint64_t expected_stride, uint64_t n_expected, uint64_t start_index,
                                int64_t* d_summary, void* hip_stream) {
@@ -769,7 +846,7 @@ int ozcs_verify_device_noalloc(int device, int type, uint32_t bpc, const void* d
   return OZCS_OK;
 }
 
-int ozcs_compute(int type, uint32_t bpc, const void* data, uint64_t len, void* sums_out, uint64_t sums_cap,
+static int compute_impl(int type, uint32_t bpc, const void* data, uint64_t len, void* sums_out, uint64_t sums_cap,
                  uint64_t* n_sums) try {
   if (n_sums) *n_sums = 0;
   int rc = check_type_bpc(type, bpc);
@@ -799,7 +876,7 @@ int ozcs_compute(int type, uint32_t bpc, const void* data, uint64_t len, void* s
   return fail(OZCS_EHIP, "unexpected failure in %s", "ozcs_compute");
 }
 
-int ozcs_verify(int type, uint32_t bpc, const void* data, uint64_t len, const void* expected,
+static int verify_impl(int type, uint32_t bpc, const void* data, uint64_t len, const void* expected,
                 uint64_t n_expected, uint64_t start_index, int64_t* first_mismatch) try {
   if (first_mismatch) *first_mismatch = -1;
   int rc = check_type_bpc(type, bpc);
@@ -820,7 +897,7 @@ int ozcs_verify(int type, uint32_t bpc, const void* data, uint64_t len, const vo
     vc.start_index = start_index;
     vc.bpc = bpc;
     vc.type = type;
-    (void)ozcs_verify_batch(&vc, 1);
+    (void)verify_batch_impl(&vc, 1);
     if (vc.status == OZCS_OK && first_mismatch) *first_mismatch = vc.first_mismatch;
     return vc.status;
   }
@@ -841,6 +918,8 @@ int ozcs_verify(int type, uint32_t bpc, const void* data, uint64_t len, const vo
   if (rc == OZCS_OK) rc = ctx_reserve(&c->d_aux, &c->aux_cap, sizeof(int64_t));
   hipError_t e = hipSuccess;
   int64_t fm = -1;
+  PhaseTimer timer(c, len);
+  timer.mark(0);
   if (rc == OZCS_OK) {
     e = hipMemcpyAsync(c->d_data, data, len, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess && ship)
@@ -849,15 +928,19 @@ int ozcs_verify(int type, uint32_t bpc, const void* data, uint64_t len, const vo
     if (e == hipSuccess) e = preset_verdicts(c->d_aux, 1, c->stream);
     if (e != hipSuccess) rc = fail_hip(e, "hipMemcpyAsync H2D");
   }
+  timer.mark(1);
   if (rc == OZCS_OK)
     rc = launch_windows(*dev, type, bpc, c->d_data, len, 1, len, kModeVerify, nullptr, c->d_sums, 0, ship, 0,
                         static_cast<unsigned long long*>(c->d_aux), c->stream);
+  timer.mark(2);
   if (rc == OZCS_OK) {
     e = hipMemcpyAsync(&fm, c->d_aux, sizeof fm, hipMemcpyDeviceToHost, c->stream);
     if (e != hipSuccess) rc = fail_hip(e, "hipMemcpyAsync D2H");
   }
+  timer.mark(3);
   e = hipStreamSynchronize(c->stream);
   if (rc == OZCS_OK && e != hipSuccess) rc = fail_hip(e, "hipStreamSynchronize");
+  if (rc == OZCS_OK) timer.finish();
   release_ctx(c);
   if (rc != OZCS_OK) return rc;
   s_h2d.fetch_add(len + ship * ds, std::memory_order_relaxed);
@@ -876,7 +959,7 @@ int ozcs_verify(int type, uint32_t bpc, const void* data, uint64_t len, const vo
   return fail(OZCS_EHIP, "unexpected failure in %s", "ozcs_verify");
 }
 
-int ozcs_compute_batch(ozcs_chunk* chunks, uint32_t n_chunks) try {
+static int compute_batch_impl(ozcs_chunk* chunks, uint32_t n_chunks) try {
   if (n_chunks == 0) return OZCS_OK;
   if (!chunks) return fail(OZCS_EINVAL, "null chunk list");
   int rc = ensure_init();
@@ -936,7 +1019,7 @@ int ozcs_compute_batch(ozcs_chunk* chunks, uint32_t n_chunks) try {
   return fail(OZCS_EHIP, "unexpected failure in %s", "ozcs_compute_batch");
 }
 
-int ozcs_verify_batch(ozcs_vchunk* v, uint32_t n_chunks) try {
+static int verify_batch_impl(ozcs_vchunk* v, uint32_t n_chunks) try {
   if (n_chunks == 0) return OZCS_OK;
   if (!v) return fail(OZCS_EINVAL, "null chunk list");
   // Hash everything that needs hashing through the batched compute path into scratch digests, then compare
@@ -960,7 +1043,7 @@ int ozcs_verify_batch(ozcs_vchunk* v, uint32_t n_chunks) try {
     append_pieces(jobs, c.type, c.bpc, c.data, c.len, sums.back().data(), ds);
     owners.push_back(Owner{i, first_job, jobs.size(), n});
   }
-  if (!jobs.empty()) (void)ozcs_compute_batch(jobs.data(), (uint32_t)jobs.size());
+  if (!jobs.empty()) (void)compute_batch_impl(jobs.data(), (uint32_t)jobs.size());
   for (size_t k = 0; k < owners.size(); k++) {
     ozcs_vchunk& c = v[owners[k].idx];
     for (size_t j = owners[k].first_job; j < owners[k].end_job && c.status == OZCS_OK; j++) c.status = jobs[j].status;
@@ -990,5 +1073,33 @@ int ozcs_verify_batch(ozcs_vchunk* v, uint32_t n_chunks) try {
 } catch (...) {
   return fail(OZCS_EHIP, "unexpected failure in %s", "ozcs_verify_batch");
 }
+
+// ---- the exported names: each counts its outcome (ozcs_get_stats) and hands it on ----
+int ozcs_init(uint32_t device_mask) { return tally(init_impl(device_mask)); }
+int ozcs_compute_device(int device, int type, uint32_t bpc, const void* d_data, uint64_t chunk_len, uint64_t n_chunks,
+                        uint64_t chunk_stride, void* d_sums, uint64_t sums_cap, void* hip_stream) {
+  return tally(compute_device_impl(device, type, bpc, d_data, chunk_len, n_chunks, chunk_stride, d_sums, sums_cap, hip_stream));
+}
+int ozcs_verify_device(int device, int type, uint32_t bpc, const void* d_data, uint64_t chunk_len, uint64_t n_chunks,
+                       uint64_t chunk_stride, const void* d_expected, uint64_t expected_stride, uint64_t n_expected,
+                       uint64_t start_index, int64_t* d_first_mismatch, void* hip_stream) {
+  return tally(verify_device_impl(device, type, bpc, d_data, chunk_len, n_chunks, chunk_stride, d_expected, expected_stride,
+                                  n_expected, start_index, d_first_mismatch, hip_stream));
+}
+int ozcs_verify_device_noalloc(int device, int type, uint32_t bpc, const void* d_data, uint64_t chunk_len,
+                               uint64_t n_chunks, uint64_t chunk_stride, const void* d_expected, uint64_t expected_stride,
+                               uint64_t n_expected, uint64_t start_index, int64_t* d_summary, void* hip_stream) {
+  return tally(verify_device_noalloc_impl(device, type, bpc, d_data, chunk_len, n_chunks, chunk_stride, d_expected,
+                                          expected_stride, n_expected, start_index, d_summary, hip_stream));
+}
+int ozcs_compute(int type, uint32_t bpc, const void* data, uint64_t len, void* sums_out, uint64_t sums_cap, uint64_t* n_sums) {
+  return tally(compute_impl(type, bpc, data, len, sums_out, sums_cap, n_sums));
+}
+int ozcs_verify(int type, uint32_t bpc, const void* data, uint64_t len, const void* expected, uint64_t n_expected,
+                uint64_t start_index, int64_t* first_mismatch) {
+  return tally(verify_impl(type, bpc, data, len, expected, n_expected, start_index, first_mismatch));
+}
+int ozcs_compute_batch(ozcs_chunk* chunks, uint32_t n_chunks) { return tally(compute_batch_impl(chunks, n_chunks)); }
+int ozcs_verify_batch(ozcs_vchunk* chunks, uint32_t n_chunks) { return tally(verify_batch_impl(chunks, n_chunks)); }
 
 }  // extern "C"

@@ -33,6 +33,23 @@ struct HostCtx {
   size_t h_stage_cap = 0;
   void* h_sums = nullptr;
   size_t h_sums_cap = 0;
+  // phase timing of sampled calls (PhaseTimer): events created on first use, and how many calls the context served
+  hipEvent_t phase[4] = {nullptr, nullptr, nullptr, nullptr};
+  uint64_t calls = 0;
+};
+
+// Times the three phases of a host-pointer call (copies in, kernels, copy back) with events on the context's
+// stream, for one call in OZCS_STATS_SAMPLE_EVERY; see ozcs_stats in the ABI header.
+class PhaseTimer {
+ public:
+  PhaseTimer(HostCtx* c, uint64_t bytes);
+  void mark(int i);   // i = 0..3, in stream order
+  void finish();      // after the stream has been synchronised and the call has succeeded
+
+ private:
+  HostCtx* c_;
+  uint64_t bytes_;
+  bool on_;
 };
 
 struct Global {
@@ -72,5 +89,9 @@ int launch_windows(const DeviceInfo& dev, int type, uint32_t bpc, const void* d_
                    unsigned long long* d_first_mismatch, hipStream_t stream);
 
 extern std::atomic<uint64_t> s_calls, s_bytes, s_windows, s_h2d, s_d2h, s_launches;
+
+// Counts a call's outcome for ozcs_get_stats and returns it unchanged.  OZCS_EBUSY is flow control; so is the
+// OZCS_EEMPTY of the pipe's "next" calls (empty_is_flow).
+int tally(int rc, bool empty_is_flow = false);
 
 }  // namespace ozcs

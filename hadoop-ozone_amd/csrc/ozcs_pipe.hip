@@ -23,6 +23,7 @@
 #include <string.h>
 
 #include <chrono>
+#include <deque>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -74,11 +75,20 @@ struct Slot {
   // threads inside ozcs_pipe_wait for a tenancy of this slot, waiting without the lock: the slot is not let
   // again before they have looked at the outcome, so the record above is always the one they need
   int waiters = 0;
+  uint64_t seq = 0;  // in-order mode: sequence number of this tenancy's entry in the outcome queue
 };
+
+// A batch gets a completion event of its own from a small ring: a thread that took a batch's event under the
+// lock and sleeps on it outside the lock wakes when THAT batch ends, even if the stream has started its next
+// batch meanwhile (one event per stream, re-recorded for every batch, made such a thread sleep through the
+// next batch as well).  The ring comes round after kBatchEvents further batches of the stream, each of which
+// lasts milliseconds and starts only after the previous one has ended.
+constexpr int kBatchEvents = 4;
 
 struct DigestStream {
   hipStream_t stream = nullptr;
-  hipEvent_t done = nullptr;  // end of the batch running on this stream
+  hipEvent_t done[kBatchEvents] = {nullptr, nullptr, nullptr, nullptr};
+  int cur = 0;                // done[cur]: end of the batch running on this stream
   bool running = false;
   std::vector<int> slots;     // slots of that batch
   DigestJob* h_jobs = nullptr;        // pinned, n_slots entries: the job list of that batch, read by the kernel in place
@@ -89,9 +99,14 @@ struct DigestStream {
 
 int make_ticket(int slot, uint32_t epoch) { return slot | (int)((epoch & kEpochMask) << kSlotBits); }
 
-// Fault injection for tests (read once): OZCS_FAULT_PIPE_DIGEST_LAUNCH = k makes the k-th digest batch launch of
-// the process fail as if the runtime had refused it.
+// Fault injection, test builds only (libozcs_testhooks.so; the product library does not read the variable):
+// OZCS_FAULT_PIPE_DIGEST_LAUNCH = k makes the k-th digest batch launch of the process fail as if the runtime had
+// refused it.
+#ifdef OZCS_TEST_HOOKS
 const int g_fault_digest_launch = getenv("OZCS_FAULT_PIPE_DIGEST_LAUNCH") ? atoi(getenv("OZCS_FAULT_PIPE_DIGEST_LAUNCH")) : 0;
+#else
+constexpr int g_fault_digest_launch = 0;
+#endif
 std::atomic<int> g_digest_launches{0};
 // Tuning override for experiments (read once): number of digest streams per pipe.  Measured on MI355X, CRC32 : MD5
 // = 3 : 1 at 1 MiB windows, 64 slots: 1 / 2 / 4 / 8 low-priority streams give 43.7 / 45.0 / 37.2 / 30.3 GB/s (the
@@ -122,6 +137,12 @@ struct ozcs_pipe {
   // batch of each algorithm was seen to take
   double last_launch_s = -1e9;
   double batch_s[2] = {0, 0};
+  // in-order mode (ozcs_pipe_set_in_order): outcomes in submission order; a slot is released when its GPU work
+  // ends and its entry here waits for ozcs_pipe_next_in_order
+  struct Outcome { int ticket; int status; uint64_t n_sums; bool done; };
+  bool in_order = false;
+  std::deque<Outcome> order;
+  uint64_t order_base = 0;  // sequence number of order.front()
   std::mutex mu;
 };
 
@@ -143,16 +164,6 @@ hipError_t query_event(hipEvent_t ev) {
   return e;
 }
 
-void mark_done(ozcs_pipe* p, Slot& s, int status) {
-  if (s.state != kInFlight) return;
-  if (status != OZCS_OK) s.status = status;
-  s.state = kDone;
-  s.deferred = false;
-  s.batch = -1;
-  p->in_flight--;
-  p->done_unclaimed++;
-}
-
 // Ends a tenancy whose slot is kDone: hands the digests over and frees the slot.
 void retire(ozcs_pipe* p, Slot& s) {
   if (s.status == OZCS_OK && s.sums_len) memcpy(s.user_sums, s.h_sums, s.sums_len);
@@ -162,6 +173,23 @@ void retire(ozcs_pipe* p, Slot& s) {
   s.has_last = true;
   s.state = kFree;
   p->done_unclaimed--;
+}
+
+void mark_done(ozcs_pipe* p, Slot& s, int status) {
+  if (s.state != kInFlight) return;
+  if (status != OZCS_OK) s.status = status;
+  s.state = kDone;
+  s.deferred = false;
+  s.batch = -1;
+  p->in_flight--;
+  p->done_unclaimed++;
+  if (p->in_order) {  // the slot goes back at once; the outcome waits in the queue for its turn
+    ozcs_pipe::Outcome& o = p->order[(size_t)(s.seq - p->order_base)];
+    o.status = s.status;
+    o.n_sums = s.n_sums;
+    o.done = true;
+    retire(p, s);
+  }
 }
 
 // Moves every slot whose GPU work has finished from kInFlight to kDone.  CRC slots complete in submission
@@ -184,7 +212,7 @@ void reap(ozcs_pipe* p) {
   }
   for (DigestStream& d : p->digest) {
     if (!d.running) continue;
-    const hipError_t e = query_event(d.done);
+    const hipError_t e = query_event(d.done[d.cur]);
     if (e == hipErrorNotReady) continue;
     const int status = e == hipSuccess ? OZCS_OK : fail_hip(e, "pipe digest batch");
     for (int t : d.slots) mark_done(p, p->slots[t], status);
@@ -208,6 +236,14 @@ void reap(ozcs_pipe* p) {
 //
 // If the runtime refuses a launch, every slot of that batch completes with the error (nothing was queued for it).
 // Caller holds p->mu, has selected the device and has called reap().
+// The pacing interval for the oldest parked slot's algorithm (see launch_deferred).
+double pacing_gap(const ozcs_pipe* p) {
+  const int type = p->slots[p->deferred[0]].type;
+  const int algo = type == OZCS_SHA256 ? kAlgoSha256 : kAlgoMd5;
+  double gap = p->batch_s[algo] / (double)p->digest.size();
+  return gap > 0.02 ? 0.02 : gap;
+}
+
 int launch_deferred(ozcs_pipe* p, bool force = false) {
   int rc = OZCS_OK;
   for (DigestStream& d : p->digest) {
@@ -217,9 +253,7 @@ int launch_deferred(ozcs_pipe* p, bool force = false) {
     const int algo = type == OZCS_SHA256 ? kAlgoSha256 : kAlgoMd5;
     const double now = now_s();
     if (!force && p->deferred.size() * 2 < p->slots.size()) {
-      double gap = p->batch_s[algo] / (double)p->digest.size();
-      if (gap > 0.02) gap = 0.02;
-      if (now - p->last_launch_s < gap) break;
+      if (now - p->last_launch_s < pacing_gap(p)) break;
     }
     uint32_t n_jobs = 0, n_windows = 0;
     d.slots.clear();
@@ -249,7 +283,9 @@ int launch_deferred(ozcs_pipe* p, bool force = false) {
       e = (g_fault_digest_launch && k == g_fault_digest_launch) ? hipErrorLaunchFailure
                                                                 : digest_launch_jobs(d.d_jobs_alias, n_jobs, n_windows, algo, p->dev.num_cus, d.stream);
     }
-    if (e == hipSuccess) e = hipEventRecord(d.done, d.stream);
+    const int ring = (d.cur + 1) % kBatchEvents;
+    if (e == hipSuccess) e = hipEventRecord(d.done[ring], d.stream);
+    if (e == hipSuccess) d.cur = ring;
     if (e != hipSuccess) {
       rc = fail_hip(e, "pipe digest batch");
       (void)hipStreamSynchronize(d.stream);  // whatever part of the batch was queued has ended before its slots are reused
@@ -276,27 +312,43 @@ int launch_deferred(ozcs_pipe* p, bool force = false) {
 // oldest running digest batch's (the one of `prefer` if it runs in one).  Null when no GPU work is queued at all.
 hipEvent_t progress_event(ozcs_pipe* p, const Slot* prefer) {
   if (prefer && prefer->state == kInFlight && !prefer->deferred) {
-    if (prefer->batch >= 0) return p->digest[prefer->batch].done;
+    if (prefer->batch >= 0) return p->digest[prefer->batch].done[p->digest[prefer->batch].cur];
     return prefer->done;
   }
   if (p->crc_head < p->crc_fifo.size()) return p->slots[p->crc_fifo[p->crc_head]].done;
   const DigestStream* first = nullptr;  // the running batch that was launched first ends first
   for (const DigestStream& d : p->digest)
     if (d.running && (!first || d.launched_s < first->launched_s)) first = &d;
-  return first ? first->done : nullptr;
+  return first ? first->done[first->cur] : nullptr;
 }
 
-// Blocks the calling thread (without the pipe's lock) until `ev` has fired -- or, while digest slots are parked,
-// for a fraction of a millisecond only: a parked slot may be waiting for nothing but the pacing interval, and a
-// sleeping caller is often the only thread that would notice it has passed.  The caller re-evaluates afterwards.
+// Blocks the calling thread (without the pipe's lock) until `ev` has fired.  One exception: while digest slots are
+// parked and a digest stream is idle, nothing but the pacing interval keeps the next batch from starting, and a
+// sleeping caller is often the only thread that would notice that it has passed -- then the thread sleeps until
+// that moment at the latest, looking at the event every 100 us without taking the lock.  The caller re-evaluates
+// afterwards.
 hipError_t wait_progress(ozcs_pipe* p, std::unique_lock<std::mutex>& lk, hipEvent_t ev) {
-  const bool parked = !p->deferred.empty();
+  double deadline = -1;
+  if (!p->deferred.empty()) {
+    bool idle = false;
+    for (const DigestStream& d : p->digest) idle = idle || !d.running;
+    if (idle) deadline = p->last_launch_s + pacing_gap(p);
+  }
   lk.unlock();
   hipError_t e = hipSuccess;
-  if (parked) {
-    std::this_thread::sleep_for(std::chrono::microseconds(200));
-  } else {
+  if (deadline < 0) {
     e = hipEventSynchronize(ev);
+  } else {
+    for (;;) {
+      e = query_event(ev);
+      if (e != hipErrorNotReady) break;
+      const double left = deadline - now_s();
+      if (left <= 0) {
+        e = hipSuccess;
+        break;
+      }
+      std::this_thread::sleep_for(std::chrono::duration<double>(left < 100e-6 ? left : 100e-6));
+    }
   }
   lk.lock();
   return e;
@@ -313,7 +365,8 @@ void destroy_pipe(ozcs_pipe* p) {
     if (s.done) (void)hipEventDestroy(s.done);
   }
   for (DigestStream& d : p->digest) {
-    if (d.done) (void)hipEventDestroy(d.done);
+    for (hipEvent_t ev : d.done)
+      if (ev) (void)hipEventDestroy(ev);
     if (d.stream) (void)hipStreamDestroy(d.stream);
     if (d.h_jobs) (void)hipHostFree(d.h_jobs);
   }
@@ -344,9 +397,38 @@ int resolve(ozcs_pipe* p, int ticket, Slot** out, bool* stale) {
   return fail(OZCS_EINVAL, "ticket %d does not name a live slot tenancy", ticket);
 }
 
+// Takes the first free slot for a new tenancy.  A slot stays its ticket holder's until that ticket has been polled
+// to completion, waited for, handed out by ozcs_pipe_next_completed or drained (or, on an in-order pipe, until its
+// GPU work has ended): a finished slot is never recycled behind its owner's back.  Caller holds p->mu.
+bool take_free_slot(ozcs_pipe* p, void** buf, int* ticket) {
+  for (size_t i = 0; i < p->slots.size(); i++) {
+    Slot& s = p->slots[i];
+    if (s.state == kFree && s.waiters == 0) {
+      s.state = kAcquired;
+      s.epoch = (s.epoch + 1) & kEpochMask;
+      *buf = s.h_data;
+      *ticket = make_ticket((int)i, s.epoch);
+      return true;
+    }
+  }
+  return false;
+}
+
+bool backlog_full(const ozcs_pipe* p) {
+  return p->in_order && p->order.size() >= (size_t)OZCS_PIPE_ORDER_BACKLOG * p->slots.size();
+}
+
+// In-order mode: the submitted slot's place in the delivery queue.  Caller holds p->mu.
+void enqueue_outcome(ozcs_pipe* p, Slot& s, int ticket) {
+  if (!p->in_order) return;
+  s.seq = p->order_base + p->order.size();
+  p->order.push_back(ozcs_pipe::Outcome{ticket, OZCS_OK, 0, false});
+}
+
 int finish(ozcs_pipe* p, int ticket, uint64_t* n_sums, bool block) {
   if (!p) return fail(OZCS_EINVAL, "null pipe");
   std::unique_lock<std::mutex> lk(p->mu);
+  if (p->in_order) return fail(OZCS_EINVAL, "the pipe delivers in order: use ozcs_pipe_next_in_order");
   DeviceGuard dg(p->device);
   for (;;) {
     Slot* sp = nullptr;
@@ -392,10 +474,11 @@ int finish(ozcs_pipe* p, int ticket, uint64_t* n_sums, bool block) {
 extern "C" {
 
 uint64_t ozcs_pipe_slot_bytes(const ozcs_pipe* pipe) { return pipe ? pipe->slot_bytes : 0; }
+uint64_t ozcs_pipe_sums_bytes(const ozcs_pipe* pipe) { return pipe ? pipe->sums_bytes : 0; }
 
 int ozcs_pipe_ticket_slot(int ticket) { return ticket < 0 ? -1 : (ticket & kSlotMask); }
 
-int ozcs_pipe_create(int device, uint32_t n_slots, uint64_t slot_bytes, ozcs_pipe** out) {
+static int pipe_create_impl(int device, uint32_t n_slots, uint64_t slot_bytes, ozcs_pipe** out) {
   if (!out) return fail(OZCS_EINVAL, "null out");
   *out = nullptr;
   if (n_slots == 0 || n_slots > (1u << kSlotBits) || slot_bytes == 0) return fail(OZCS_EINVAL, "bad pipe geometry");
@@ -430,7 +513,8 @@ int ozcs_pipe_create(int device, uint32_t n_slots, uint64_t slot_bytes, ozcs_pip
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->s_kernel, hipStreamNonBlocking);
   for (DigestStream& d : p->digest) {
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&d.stream, hipStreamNonBlocking, g_digest_low_prio ? prio_low : 0);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&d.done, hipEventDisableTiming);
+    for (hipEvent_t& ev : d.done)
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&d.h_jobs), sizeof(DigestJob) * n_slots, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&d.d_jobs_alias), d.h_jobs, 0);
   }
@@ -464,30 +548,96 @@ void ozcs_pipe_destroy(ozcs_pipe* p) {
   destroy_pipe(p);
 }
 
-int ozcs_pipe_acquire(ozcs_pipe* p, void** buf, int* ticket) {
+static int pipe_acquire_impl(ozcs_pipe* p, void** buf, int* ticket) {
   if (!p || !buf || !ticket) return fail(OZCS_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(p->mu);
-  // A slot stays its ticket holder's until that ticket has been polled to completion, waited for, handed out by
-  // ozcs_pipe_next_completed or drained: a finished slot is never recycled behind its owner's back.
-  for (size_t i = 0; i < p->slots.size(); i++) {
-    Slot& s = p->slots[i];
-    if (s.state == kFree && s.waiters == 0) {
-      s.state = kAcquired;
-      s.epoch = (s.epoch + 1) & kEpochMask;
-      *buf = s.h_data;
-      *ticket = make_ticket((int)i, s.epoch);
-      return OZCS_OK;
-    }
-  }
-  if (!p->deferred.empty()) {  // parked digest slots finish only once launched
+  if (backlog_full(p)) return fail(OZCS_EBUSY, "%zu outcomes wait for ozcs_pipe_next_in_order", p->order.size());
+  if (take_free_slot(p, buf, ticket)) return OZCS_OK;
+  {  // completed slots of an in-order pipe go back by themselves; parked digest slots finish only once launched
     DeviceGuard dg(p->device);
     reap(p);
-    (void)launch_deferred(p);
+    if (!p->deferred.empty()) (void)launch_deferred(p);
   }
+  if (p->in_order && take_free_slot(p, buf, ticket)) return OZCS_OK;
   return fail(OZCS_EBUSY, "all %zu slots are held", p->slots.size());
 }
 
-int ozcs_pipe_submit_slot(ozcs_pipe* p, int ticket, int type, uint32_t bpc, uint64_t len, void* sums_out,
+static int pipe_acquire_wait_impl(ozcs_pipe* p, void** buf, int* ticket) {
+  if (!p || !buf || !ticket) return fail(OZCS_EINVAL, "null argument");
+  std::unique_lock<std::mutex> lk(p->mu);
+  DeviceGuard dg(p->device);
+  for (;;) {
+    if (backlog_full(p)) return fail(OZCS_EBUSY, "%zu outcomes wait for ozcs_pipe_next_in_order", p->order.size());
+    if (take_free_slot(p, buf, ticket)) return OZCS_OK;
+    reap(p);
+    if (!p->deferred.empty()) (void)launch_deferred(p);
+    if (p->in_order && take_free_slot(p, buf, ticket)) return OZCS_OK;
+    // waiting helps only where the library itself hands slots back, and only while GPU work is pending
+    if (!p->in_order || p->in_flight == 0) return fail(OZCS_EBUSY, "all %zu slots are held", p->slots.size());
+    hipEvent_t ev = progress_event(p, nullptr);
+    if (!ev) {  // only parked slots are in flight: start them
+      (void)launch_deferred(p, true);
+      continue;
+    }
+    const hipError_t e = wait_progress(p, lk, ev);
+    if (e != hipSuccess) return fail_hip(e, "pipe completion");
+  }
+}
+
+static int pipe_release_impl(ozcs_pipe* p, int ticket) {
+  if (!p) return fail(OZCS_EINVAL, "null pipe");
+  std::lock_guard<std::mutex> lk(p->mu);
+  Slot* sp = nullptr;
+  bool stale = false;
+  if (resolve(p, ticket, &sp, &stale) != OZCS_OK || stale || sp->state != kAcquired)
+    return fail(OZCS_EINVAL, "ticket %d is not an acquired slot", ticket);
+  sp->state = kFree;
+  return OZCS_OK;
+}
+
+static int pipe_set_in_order_impl(ozcs_pipe* p, int on) {
+  if (!p) return fail(OZCS_EINVAL, "null pipe");
+  std::lock_guard<std::mutex> lk(p->mu);
+  if (p->in_flight || p->done_unclaimed || !p->order.empty())
+    return fail(OZCS_EBUSY, "the delivery mode changes only while no ticket is outstanding");
+  p->in_order = on != 0;
+  return OZCS_OK;
+}
+
+static int pipe_next_in_order_impl(ozcs_pipe* p, int block, int* ticket, int* status, uint64_t* n_sums) {
+  if (!p || !ticket) return fail(OZCS_EINVAL, "null argument");
+  std::unique_lock<std::mutex> lk(p->mu);
+  if (!p->in_order) return fail(OZCS_EINVAL, "the pipe is not in in-order mode (ozcs_pipe_set_in_order)");
+  DeviceGuard dg(p->device);
+  for (;;) {
+    if (p->order.empty()) return fail(OZCS_EEMPTY, "no submitted ticket is outstanding");
+    reap(p);
+    const ozcs_pipe::Outcome head = p->order.front();
+    if (head.done) {
+      p->order.pop_front();
+      p->order_base++;
+      *ticket = head.ticket;
+      if (status) *status = head.status;
+      if (n_sums) *n_sums = head.n_sums;
+      if (!p->deferred.empty()) (void)launch_deferred(p);
+      return OZCS_OK;
+    }
+    // the head is in flight, so its slot still holds that tenancy
+    Slot& s = p->slots[(size_t)(head.ticket & kSlotMask)];
+    if (!p->deferred.empty()) (void)launch_deferred(p, block && s.deferred);
+    if (p->order.front().done) continue;  // a refused launch completes its tickets with the error
+    if (!block) return OZCS_EBUSY;
+    hipEvent_t ev = progress_event(p, &s);
+    if (!ev) return fail(OZCS_EHIP, "ticket %d is in flight but no GPU work is queued", head.ticket);
+    const hipError_t e = wait_progress(p, lk, ev);
+    if (e != hipSuccess) {
+      if (!p->order.empty() && p->order.front().ticket == head.ticket && !p->order.front().done && s.state == kInFlight)
+        mark_done(p, s, fail_hip(e, "pipe completion"));
+    }
+  }
+}
+
+static int pipe_submit_slot_impl(ozcs_pipe* p, int ticket, int type, uint32_t bpc, uint64_t len, void* sums_out,
                           uint64_t sums_cap) {
   if (!p) return fail(OZCS_EINVAL, "null pipe");
   std::lock_guard<std::mutex> lk(p->mu);
@@ -526,6 +676,7 @@ int ozcs_pipe_submit_slot(ozcs_pipe* p, int ticket, int type, uint32_t bpc, uint
     s.deferred = true;
     s.state = kInFlight;
     p->in_flight++;
+    enqueue_outcome(p, s, ticket);
     p->deferred.push_back(ticket & kSlotMask);
     s_h2d.fetch_add(len, std::memory_order_relaxed);
     s_d2h.fetch_add(n * ds, std::memory_order_relaxed);
@@ -552,28 +703,30 @@ int ozcs_pipe_submit_slot(ozcs_pipe* p, int ticket, int type, uint32_t bpc, uint
   }
   s.state = kInFlight;
   p->in_flight++;
+  enqueue_outcome(p, s, ticket);
   p->crc_fifo.push_back(ticket & kSlotMask);
   if (!p->deferred.empty()) (void)launch_deferred(p);  // a digest stream may have become idle meanwhile
   return OZCS_OK;
 }
 
-int ozcs_pipe_submit(ozcs_pipe* p, int type, uint32_t bpc, const void* data, uint64_t len, void* sums_out,
+static int pipe_submit_impl(ozcs_pipe* p, int type, uint32_t bpc, const void* data, uint64_t len, void* sums_out,
                      uint64_t sums_cap, int* ticket) {
   if (!p || !ticket || (!data && len)) return fail(OZCS_EINVAL, "null argument");
   if (len > p->slot_bytes) return fail(OZCS_EINVAL, "len exceeds the slot size");
   void* buf = nullptr;
-  int rc = ozcs_pipe_acquire(p, &buf, ticket);
+  int rc = pipe_acquire_impl(p, &buf, ticket);
   if (rc != OZCS_OK) return rc;
   if (len) memcpy(buf, data, len);
-  return ozcs_pipe_submit_slot(p, *ticket, type, bpc, len, sums_out, sums_cap);
+  return pipe_submit_slot_impl(p, *ticket, type, bpc, len, sums_out, sums_cap);
 }
 
-int ozcs_pipe_poll(ozcs_pipe* p, int ticket, uint64_t* n_sums) { return finish(p, ticket, n_sums, false); }
-int ozcs_pipe_wait(ozcs_pipe* p, int ticket, uint64_t* n_sums) { return finish(p, ticket, n_sums, true); }
+int ozcs_pipe_poll(ozcs_pipe* p, int ticket, uint64_t* n_sums) { return tally(finish(p, ticket, n_sums, false)); }
+int ozcs_pipe_wait(ozcs_pipe* p, int ticket, uint64_t* n_sums) { return tally(finish(p, ticket, n_sums, true)); }
 
-int ozcs_pipe_next_completed(ozcs_pipe* p, int block, int* ticket, int* status, uint64_t* n_sums) {
+static int pipe_next_completed_impl(ozcs_pipe* p, int block, int* ticket, int* status, uint64_t* n_sums) {
   if (!p || !ticket) return fail(OZCS_EINVAL, "null argument");
   std::unique_lock<std::mutex> lk(p->mu);
+  if (p->in_order) return fail(OZCS_EINVAL, "the pipe delivers in order: use ozcs_pipe_next_in_order");
   DeviceGuard dg(p->device);
   for (;;) {
     reap(p);
@@ -602,7 +755,7 @@ int ozcs_pipe_next_completed(ozcs_pipe* p, int block, int* ticket, int* status, 
   }
 }
 
-int ozcs_pipe_drain(ozcs_pipe* p) {
+static int pipe_drain_impl(ozcs_pipe* p) {
   if (!p) return fail(OZCS_EINVAL, "null pipe");
   std::unique_lock<std::mutex> lk(p->mu);
   DeviceGuard dg(p->device);
@@ -615,7 +768,11 @@ int ozcs_pipe_drain(ozcs_pipe* p) {
       if (s.status != OZCS_OK && rc == OZCS_OK) rc = s.status;
       retire(p, s);
     }
-    if (p->in_flight == 0) return rc;
+    if (p->in_flight == 0) {
+      for (const ozcs_pipe::Outcome& o : p->order)
+        if (o.status != OZCS_OK && rc == OZCS_OK) rc = o.status;
+      return rc;
+    }
     hipEvent_t ev = progress_event(p, nullptr);
     if (!ev && !p->deferred.empty()) {  // only parked slots are left: nothing to wait for until they are launched
       (void)launch_deferred(p, true);
@@ -626,5 +783,29 @@ int ozcs_pipe_drain(ozcs_pipe* p) {
     if (e != hipSuccess) return fail_hip(e, "pipe drain");
   }
 }
+
+// ---- the exported names: each counts its outcome (ozcs_get_stats) and hands it on ----
+int ozcs_pipe_create(int device, uint32_t n_slots, uint64_t slot_bytes, ozcs_pipe** out) {
+  return tally(pipe_create_impl(device, n_slots, slot_bytes, out));
+}
+int ozcs_pipe_acquire(ozcs_pipe* p, void** buf, int* ticket) { return tally(pipe_acquire_impl(p, buf, ticket)); }
+int ozcs_pipe_acquire_wait(ozcs_pipe* p, void** buf, int* ticket) { return tally(pipe_acquire_wait_impl(p, buf, ticket)); }
+int ozcs_pipe_release(ozcs_pipe* p, int ticket) { return tally(pipe_release_impl(p, ticket)); }
+int ozcs_pipe_submit_slot(ozcs_pipe* p, int ticket, int type, uint32_t bpc, uint64_t len, void* sums_out,
+                          uint64_t sums_cap) {
+  return tally(pipe_submit_slot_impl(p, ticket, type, bpc, len, sums_out, sums_cap));
+}
+int ozcs_pipe_submit(ozcs_pipe* p, int type, uint32_t bpc, const void* data, uint64_t len, void* sums_out,
+                     uint64_t sums_cap, int* ticket) {
+  return tally(pipe_submit_impl(p, type, bpc, data, len, sums_out, sums_cap, ticket));
+}
+int ozcs_pipe_next_completed(ozcs_pipe* p, int block, int* ticket, int* status, uint64_t* n_sums) {
+  return tally(pipe_next_completed_impl(p, block, ticket, status, n_sums), /*empty_is_flow=*/true);
+}
+int ozcs_pipe_set_in_order(ozcs_pipe* p, int on) { return tally(pipe_set_in_order_impl(p, on)); }
+int ozcs_pipe_next_in_order(ozcs_pipe* p, int block, int* ticket, int* status, uint64_t* n_sums) {
+  return tally(pipe_next_in_order_impl(p, block, ticket, status, n_sums), /*empty_is_flow=*/true);
+}
+int ozcs_pipe_drain(ozcs_pipe* p) { return tally(pipe_drain_impl(p)); }
 
 }  // extern "C"

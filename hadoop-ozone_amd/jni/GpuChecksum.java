@@ -7,9 +7,28 @@
 package org.apache.hadoop.ozone.common;
 
 import java.nio.ByteBuffer;
+import java.util.List;
+
+import org.apache.hadoop.hdds.protocol.datanode.proto.ContainerProtos.ChecksumType;
+import org.apache.ratis.thirdparty.com.google.protobuf.ByteString;
 
 public final class GpuChecksum {
   private static final boolean AVAILABLE;
+
+  /** Calls with fewer bytes than this stay on the Java engines (one PCIe round trip costs more than a small CRC). */
+  private static final long MIN_BYTES = Long.getLong("ozone.gpu.checksum.min.bytes", 0L);
+  /** Geometry of the process-wide pinned pipe that carries non-direct buffers to the GPU. */
+  private static final int PIPE_SLOTS = Integer.getInteger("ozone.gpu.checksum.pipe.slots", 16);
+  private static final long PIPE_SLOT_BYTES = Long.getLong("ozone.gpu.checksum.pipe.slot.bytes", 8L << 20);
+
+  private static final Object PIPE_LOCK = new Object();
+  private static long sharedPipe;          // 0 until created
+  private static boolean sharedPipeFailed; // creation was tried and refused: do not try again
+  private static long sharedSlotBytes;
+  private static long sharedSumsBytes;
+
+  /** Per-thread direct buffer the digests of one computeWindows call come back in. */
+  private static final ThreadLocal<ByteBuffer> SUMS = new ThreadLocal<>();
 
   static {
     boolean ok = false;
@@ -27,6 +46,181 @@ public final class GpuChecksum {
   /** True when a gfx950 device is usable; callers keep the pure-Java path otherwise. */
   public static boolean isAvailable() {
     return AVAILABLE;
+  }
+
+  /**
+   * The per-window loop of Checksum.computeChecksum(ChunkBuffer) in one pass over the GPU.  {@code windows} are the
+   * buffers {@code data.iterate(bytesPerChecksum)} handed out, in order; each contributes the digest of at most
+   * {@code bytesPerSum} bytes from its position (the clamp of Checksum.computeChecksum(ByteBuffer, Function, int)).
+   * Whatever kind the buffers are, their bytes reach the library:
+   * <ul>
+   * <li>direct buffers (read-only ones included) are used in place, all windows in one native call;</li>
+   * <li>everything else -- heap buffers and the read-only heap views that computeChecksum(byte[]),
+   *     computeChecksum(ByteBuffer), computeChecksum(List&lt;ByteString&gt;) and every verifyChecksum overload produce,
+   *     which offer neither array() nor an address -- is copied once, with ByteBuffer.put, into pinned slots of a
+   *     process-wide pipe (the one copy ChecksumByteBufferImpl.update pays for such buffers today) and checksummed
+   *     from there, several slots in flight.</li>
+   * </ul>
+   * On success the digests are appended to {@code out}, one ByteString per window, each window buffer is left where
+   * the Java function would have left it, and true is returned.  On false nothing was appended and no buffer was
+   * touched: the caller runs its Java loop over the same windows (library unavailable, a window larger than a pipe
+   * slot, every slot held by other threads, an empty window, fewer than ozone.gpu.checksum.min.bytes bytes).
+   */
+  public static boolean computeWindows(ChecksumType checksumType, int bytesPerSum, List<ByteBuffer> windows,
+      List<ByteString> out) {
+    final int type = checksumType.getNumber();
+    final int ds = digestSize(type);
+    final int n = windows.size();
+    if (!AVAILABLE || ds == 0 || bytesPerSum <= 0 || n == 0 || (long) n * ds > Integer.MAX_VALUE) {
+      return false;
+    }
+    final int[] lens = new int[n];
+    long total = 0;
+    boolean allDirect = true;
+    for (int i = 0; i < n; i++) {
+      final ByteBuffer w = windows.get(i);
+      lens[i] = Math.min(w.remaining(), bytesPerSum);
+      if (lens[i] == 0) {
+        return false;   // the digest of no bytes: rare (a consumed buffer of an IncrementalChunkBuffer); Java does it
+      }
+      total += lens[i];
+      allDirect &= w.isDirect();
+    }
+    if (total < MIN_BYTES) {
+      return false;
+    }
+    final ByteBuffer sums = sumsBuffer(n * ds);
+    final boolean ok = allDirect ? sumsOfDirectWindows(type, bytesPerSum, windows, lens, sums)
+        : sumsThroughPipe(type, bytesPerSum, windows, lens, sums, ds);
+    if (!ok) {
+      return false;
+    }
+    final byte[] raw = new byte[n * ds];
+    sums.position(0).limit(n * ds);
+    sums.get(raw);
+    for (int i = 0; i < n; i++) {
+      out.add(ByteString.copyFrom(raw, i * ds, ds));
+    }
+    // MessageDigest.update(ByteBuffer) consumes what it hashes; ChecksumByteBufferImpl.update consumes only buffers
+    // without an accessible array (ChecksumByteBufferImpl.java:38-47)
+    final boolean digest = type == 4 || type == 5;
+    for (int i = 0; i < n; i++) {
+      final ByteBuffer w = windows.get(i);
+      if (digest || !w.hasArray()) {
+        w.position(w.position() + lens[i]);
+      }
+    }
+    return true;
+  }
+
+  private static ByteBuffer sumsBuffer(int bytes) {
+    ByteBuffer b = SUMS.get();
+    if (b == null || b.capacity() < bytes) {
+      b = ByteBuffer.allocateDirect(Math.max(bytes, 4096));
+      SUMS.set(b);
+    }
+    b.clear();
+    return b;
+  }
+
+  private static boolean sumsOfDirectWindows(int type, int bytesPerSum, List<ByteBuffer> windows, int[] lens,
+      ByteBuffer sums) {
+    final int n = lens.length;
+    final ByteBuffer[] w = new ByteBuffer[n];
+    final int[] positions = new int[n];
+    final int[] limits = new int[n];
+    for (int i = 0; i < n; i++) {
+      w[i] = windows.get(i);
+      positions[i] = w[i].position();
+      limits[i] = positions[i] + lens[i];
+    }
+    return calculateWindowSumsDirect(bytesPerSum, type, sums, 0, sums.capacity(), w, positions, limits) == n;
+  }
+
+  /** The process-wide pipe for non-direct buffers, created on first use; 0 when it cannot be had. */
+  private static long sharedPipe() {
+    synchronized (PIPE_LOCK) {
+      if (sharedPipe == 0 && !sharedPipeFailed) {
+        sharedPipe = pipeCreate(0, PIPE_SLOTS, PIPE_SLOT_BYTES);
+        if (sharedPipe == 0) {
+          sharedPipeFailed = true;
+        } else {
+          sharedSlotBytes = pipeSlotBytes(sharedPipe);
+          sharedSumsBytes = pipeSumsBytes(sharedPipe);
+        }
+      }
+      return sharedPipe;
+    }
+  }
+
+  /**
+   * Windows are packed back to back into pinned slots; a slot is submitted as one chunk of bytesPerSum windows, so
+   * a window shorter than bytesPerSum ends its slot's group (only the last window of a chunk may be short).  Slots
+   * are submitted as they fill and all waited for at the end, so copies, transfers and kernels of one call overlap.
+   */
+  private static boolean sumsThroughPipe(int type, int bytesPerSum, List<ByteBuffer> windows, int[] lens,
+      ByteBuffer sums, int ds) {
+    final long pipe = sharedPipe();
+    if (pipe == 0) {
+      return false;
+    }
+    final int n = lens.length;
+    for (int i = 0; i < n; i++) {
+      if (lens[i] > sharedSlotBytes) {
+        return false;
+      }
+    }
+    final int maxWindowsPerSlot = (int) Math.min(Integer.MAX_VALUE, sharedSumsBytes / ds);
+    final int[] tickets = new int[n];
+    final int[] counts = new int[n];
+    final int[] ticketOut = new int[1];
+    int groups = 0;
+    int harvested = 0;
+    boolean ok = true;
+    int i = 0;
+    while (ok && i < n) {
+      ByteBuffer slot = pipeAcquire(pipe, ticketOut);
+      while (slot == null && harvested < groups) {   // every slot is busy: our own oldest group gives one back
+        ok &= pipeWait(pipe, tickets[harvested]) == counts[harvested];
+        harvested++;
+        slot = pipeAcquire(pipe, ticketOut);
+      }
+      if (slot == null) {
+        ok = false;                                  // other threads hold every slot: this call stays on the CPU
+        break;
+      }
+      final int first = i;
+      int filled = 0;
+      try {
+        while (i < n && i - first < maxWindowsPerSlot && filled + lens[i] <= slot.capacity()) {
+          final ByteBuffer w = windows.get(i).duplicate();
+          w.limit(w.position() + lens[i]);
+          slot.put(w);
+          filled += lens[i];
+          i++;
+          if (lens[i - 1] < bytesPerSum) {
+            break;
+          }
+        }
+      } catch (RuntimeException e) {
+        pipeRelease(pipe, ticketOut[0]);
+        throw e;
+      }
+      final ByteBuffer s = sums.duplicate();
+      s.position(first * ds).limit(i * ds);
+      if (pipeSubmit(pipe, ticketOut[0], type, bytesPerSum, filled, s.slice()) == 0) {
+        tickets[groups] = ticketOut[0];
+        counts[groups] = i - first;
+        groups++;
+      } else {
+        ok = false;                                  // a rejected submission has released its slot
+      }
+    }
+    while (harvested < groups) {                     // also after a failure: the digests land in this thread's buffer
+      ok &= pipeWait(pipe, tickets[harvested]) == counts[harvested];
+      harvested++;
+    }
+    return ok;
   }
 
   /** ozcs_digest_size. */
@@ -110,6 +304,19 @@ public final class GpuChecksum {
   public static native long pipeNextCompleted(long pipe, boolean block, int[] ticketStatusOut);
   /** The slot number (0 .. slots-1) behind a ticket, for per-slot state on the Java side. */
   public static native int pipeTicketSlot(int ticket);
+  /** Hands back an acquired slot that will not be submitted. */
+  public static native int pipeRelease(long pipe, int ticket);
+  /** Capacity of every slot's chunk buffer / of the digest buffer behind it (bounds the windows one slot can take). */
+  public static native long pipeSlotBytes(long pipe);
+  public static native long pipeSumsBytes(long pipe);
+  /**
+   * In-order delivery (ozcs_pipe_set_in_order): slots go back to the pool when the GPU is done with them and outcomes
+   * are handed out in submission order by pipeNextInOrder -- for a BlockOutputStream that has copied the chunk into
+   * its request (chunk.toByteString) and sends requests in order.  pipeAcquireWait blocks for a slot.
+   */
+  public static native int pipeSetInOrder(long pipe, boolean on);
+  public static native long pipeNextInOrder(long pipe, boolean block, int[] ticketStatusOut);
+  public static native ByteBuffer pipeAcquireWait(long pipe, int[] ticketOut);
 
   private static native boolean nativeAvailable();
 }

@@ -61,13 +61,18 @@ JNIEXPORT jlong JNICALL JFN(calculateChunkedSumsByteArray)(JNIEnv* env, jclass c
   void* slot = NULL;
   int ticket = -1;
   pthread_once(&g_pipe_once, make_pipe);
-  if (g_pipe && (uint64_t)dataLen <= SHIM_SLOT_BYTES && n * ds <= (SHIM_SLOT_BYTES / 512 + 1) * 32 &&
+  if (g_pipe && (uint64_t)dataLen <= SHIM_SLOT_BYTES && n * ds <= ozcs_pipe_sums_bytes(g_pipe) &&
       ozcs_pipe_acquire(g_pipe, &slot, &ticket) == OZCS_OK) {
     /* Java heap -> pinned slot in one copy, then copy + kernel through the pipe */
     (*env)->GetByteArrayRegion(env, data, dataOff, dataLen, (jbyte*)slot);
-    int rc = ozcs_pipe_submit_slot(g_pipe, ticket, type, (uint32_t)bpc, (uint64_t)dataLen, out, n * ds);
-    if (rc == OZCS_OK) rc = ozcs_pipe_wait(g_pipe, ticket, &got);
-    result = sums_to_array(env, rc, got, type, out, sums, sumsOff);
+    if ((*env)->ExceptionCheck(env)) {  /* the range was checked above, so none is expected */
+      (void)ozcs_pipe_release(g_pipe, ticket);
+      result = OZCS_EINVAL;
+    } else {
+      int rc = ozcs_pipe_submit_slot(g_pipe, ticket, type, (uint32_t)bpc, (uint64_t)dataLen, out, n * ds);
+      if (rc == OZCS_OK) rc = ozcs_pipe_wait(g_pipe, ticket, &got);
+      result = sums_to_array(env, rc, got, type, out, sums, sumsOff);
+    }
   } else {
     uint8_t* d = (uint8_t*)malloc((size_t)dataLen);
     if (!d) {
@@ -75,8 +80,12 @@ JNIEXPORT jlong JNICALL JFN(calculateChunkedSumsByteArray)(JNIEnv* env, jclass c
       return OZCS_ENOMEM;
     }
     (*env)->GetByteArrayRegion(env, data, dataOff, dataLen, (jbyte*)d);
-    const int rc = ozcs_compute(type, (uint32_t)bpc, d, (uint64_t)dataLen, out, n * ds, &got);
-    result = sums_to_array(env, rc, got, type, out, sums, sumsOff);
+    if ((*env)->ExceptionCheck(env)) {
+      result = OZCS_EINVAL;
+    } else {
+      const int rc = ozcs_compute(type, (uint32_t)bpc, d, (uint64_t)dataLen, out, n * ds, &got);
+      result = sums_to_array(env, rc, got, type, out, sums, sumsOff);
+    }
     free(d);
   }
   free(out);
@@ -99,7 +108,15 @@ JNIEXPORT jlong JNICALL JFN(calculateChunkedSumsDirect)(JNIEnv* env, jclass cls,
 
 /* One window per direct buffer, each cut to bytesPerSum bytes (Checksum.java:186-198) and empty ones skipped, as
  * ChunkBufferImplWithByteBufferList.iterate hands them out: the List<ByteString> / list-backed ChunkBuffer case in
- * ONE ozcs_compute_batch call.  Digests go to sums[sumsPos ...] back to back; returns their count. */
+ * one library call.  Digests go to sums[sumsPos ...] back to back; returns their count.
+ *
+ * Local references: every GetObjectArrayElement creates one and a native frame is only guaranteed 16, so each is
+ * deleted as soon as the buffer's address has been taken (the address stays valid: the Java array keeps the
+ * buffer alive for the duration of the call).
+ *
+ * Windows that turn out to lie back to back in memory, all bytesPerSum long except possibly the last -- the
+ * slices ChunkBufferImplWithByteBuffer.iterate cuts from one direct buffer -- are one chunk: they go to
+ * ozcs_compute as such (one copy, one launch) instead of one descriptor each. */
 JNIEXPORT jlong JNICALL JFN(calculateWindowSumsDirect)(JNIEnv* env, jclass cls, jint bpc, jint type,
     jobject sums, jint sumsPos, jint sumsLimit, jobjectArray windows, jintArray positions, jintArray limits) {
   (void)cls;
@@ -117,15 +134,23 @@ JNIEXPORT jlong JNICALL JFN(calculateWindowSumsDirect)(JNIEnv* env, jclass cls, 
     free(pl);
     return OZCS_ENOMEM;
   }
-  (*env)->GetIntArrayRegion(env, positions, 0, n, pl);
-  (*env)->GetIntArrayRegion(env, limits, 0, n, pl + n);
   jlong result = 0;
+  (*env)->GetIntArrayRegion(env, positions, 0, n, pl);
+  if (!(*env)->ExceptionCheck(env)) (*env)->GetIntArrayRegion(env, limits, 0, n, pl + n);
+  if ((*env)->ExceptionCheck(env)) result = OZCS_EINVAL;
   uint32_t k = 0;
+  int one_chunk = 1;  /* so far the windows lie back to back and all but the last are bpc long */
   for (jsize i = 0; i < n && result == 0; i++) {
     jobject w = (*env)->GetObjectArrayElement(env, windows, i);
+    if ((*env)->ExceptionCheck(env)) {
+      result = OZCS_EINVAL;
+      break;
+    }
     uint8_t* d = w ? (uint8_t*)(*env)->GetDirectBufferAddress(env, w) : NULL;
+    const jlong cap = w ? (*env)->GetDirectBufferCapacity(env, w) : -1;
+    if (w) (*env)->DeleteLocalRef(env, w);
     const jint pos = pl[i], lim = pl[n + i];
-    if (!d || pos < 0 || lim < pos || lim > (*env)->GetDirectBufferCapacity(env, w)) {
+    if (!d || pos < 0 || lim < pos || lim > cap) {
       result = OZCS_EINVAL;
     } else if (lim > pos) {
       if ((jlong)sumsPos + (jlong)((k + 1) * ds) > sumsLimit) {
@@ -138,11 +163,20 @@ JNIEXPORT jlong JNICALL JFN(calculateWindowSumsDirect)(JNIEnv* env, jclass cls, 
       jobs[k].sums_cap = ds;
       jobs[k].bpc = (uint32_t)bpc;
       jobs[k].type = type;
+      if (k && (jobs[k - 1].len != (uint64_t)bpc || (const uint8_t*)jobs[k - 1].data + bpc != d + pos)) one_chunk = 0;
       k++;
     }
   }
   if (result == 0 && k) {
-    const int rc = ozcs_compute_batch(jobs, k);
+    int rc;
+    if (one_chunk && k > 1) {
+      uint64_t got = 0;
+      rc = ozcs_compute(type, (uint32_t)bpc, jobs[0].data, (uint64_t)(k - 1) * (uint64_t)bpc + jobs[k - 1].len, s + sumsPos,
+                        (uint64_t)k * ds, &got);
+      if (rc == OZCS_OK && got != k) rc = OZCS_EINVAL;
+    } else {
+      rc = ozcs_compute_batch(jobs, k);
+    }
     result = rc == OZCS_OK ? (jlong)k : (jlong)rc;
   }
   free(jobs);
@@ -163,8 +197,8 @@ JNIEXPORT jlong JNICALL JFN(verifyChunkedSumsByteArray)(JNIEnv* env, jclass cls,
   int rc = OZCS_ENOMEM;
   if (d && s) {
     (*env)->GetByteArrayRegion(env, data, dataOff, dataLen, (jbyte*)d);
-    (*env)->GetByteArrayRegion(env, sums, sumsOff, (jsize)sumBytes, (jbyte*)s);
-    rc = ozcs_verify(type, (uint32_t)bpc, d, (uint64_t)dataLen, s, (uint64_t)numSums, (uint64_t)startIndex, &first);
+    if (!(*env)->ExceptionCheck(env)) (*env)->GetByteArrayRegion(env, sums, sumsOff, (jsize)sumBytes, (jbyte*)s);
+    rc = (*env)->ExceptionCheck(env) ? OZCS_EINVAL : ozcs_verify(type, (uint32_t)bpc, d, (uint64_t)dataLen, s, (uint64_t)numSums, (uint64_t)startIndex, &first);
   }
   free(d);
   free(s);
@@ -206,7 +240,58 @@ JNIEXPORT jobject JNICALL JFN(pipeAcquire)(JNIEnv* env, jclass cls, jlong pipe, 
   if (ozcs_pipe_acquire((ozcs_pipe*)(intptr_t)pipe, &buf, &ticket) != OZCS_OK) return NULL;
   const jint t = ticket;
   (*env)->SetIntArrayRegion(env, ticketOut, 0, 1, &t);
+  if ((*env)->ExceptionCheck(env)) {  /* ticketOut too short: the caller never learns the ticket */
+    (void)ozcs_pipe_release((ozcs_pipe*)(intptr_t)pipe, ticket);
+    return NULL;
+  }
   return (*env)->NewDirectByteBuffer(env, buf, (jlong)ozcs_pipe_slot_bytes((ozcs_pipe*)(intptr_t)pipe));
+}
+
+JNIEXPORT jobject JNICALL JFN(pipeAcquireWait)(JNIEnv* env, jclass cls, jlong pipe, jintArray ticketOut) {
+  (void)cls;
+  void* buf = NULL;
+  int ticket = -1;
+  if (ozcs_pipe_acquire_wait((ozcs_pipe*)(intptr_t)pipe, &buf, &ticket) != OZCS_OK) return NULL;
+  const jint t = ticket;
+  (*env)->SetIntArrayRegion(env, ticketOut, 0, 1, &t);
+  if ((*env)->ExceptionCheck(env)) {  /* ticketOut too short: the caller never learns the ticket */
+    (void)ozcs_pipe_release((ozcs_pipe*)(intptr_t)pipe, ticket);
+    return NULL;
+  }
+  return (*env)->NewDirectByteBuffer(env, buf, (jlong)ozcs_pipe_slot_bytes((ozcs_pipe*)(intptr_t)pipe));
+}
+
+JNIEXPORT jint JNICALL JFN(pipeRelease)(JNIEnv* env, jclass cls, jlong pipe, jint ticket) {
+  (void)env; (void)cls;
+  return ozcs_pipe_release((ozcs_pipe*)(intptr_t)pipe, ticket);
+}
+
+JNIEXPORT jlong JNICALL JFN(pipeSlotBytes)(JNIEnv* env, jclass cls, jlong pipe) {
+  (void)env; (void)cls;
+  return (jlong)ozcs_pipe_slot_bytes((ozcs_pipe*)(intptr_t)pipe);
+}
+
+JNIEXPORT jlong JNICALL JFN(pipeSumsBytes)(JNIEnv* env, jclass cls, jlong pipe) {
+  (void)env; (void)cls;
+  return (jlong)ozcs_pipe_sums_bytes((ozcs_pipe*)(intptr_t)pipe);
+}
+
+JNIEXPORT jint JNICALL JFN(pipeSetInOrder)(JNIEnv* env, jclass cls, jlong pipe, jboolean on) {
+  (void)env; (void)cls;
+  return ozcs_pipe_set_in_order((ozcs_pipe*)(intptr_t)pipe, on ? 1 : 0);
+}
+
+/* As pipeNextCompleted, but the oldest submitted ticket only (OZCS_EBUSY while it is in flight and block is false). */
+JNIEXPORT jlong JNICALL JFN(pipeNextInOrder)(JNIEnv* env, jclass cls, jlong pipe, jboolean block, jintArray ticketStatusOut) {
+  (void)cls;
+  if ((*env)->GetArrayLength(env, ticketStatusOut) < 2) return OZCS_EINVAL;  /* before an outcome is consumed */
+  int ticket = -1, status = OZCS_OK;
+  uint64_t n = 0;
+  const int rc = ozcs_pipe_next_in_order((ozcs_pipe*)(intptr_t)pipe, block ? 1 : 0, &ticket, &status, &n);
+  if (rc != OZCS_OK) return (jlong)rc;
+  const jint out[2] = {ticket, status};
+  (*env)->SetIntArrayRegion(env, ticketStatusOut, 0, 2, out);
+  return (jlong)n;
 }
 
 JNIEXPORT jint JNICALL JFN(pipeSubmit)(JNIEnv* env, jclass cls, jlong pipe, jint ticket, jint type, jint bpc,
@@ -231,6 +316,7 @@ JNIEXPORT jlong JNICALL JFN(pipeNextCompleted)(JNIEnv* env, jclass cls, jlong pi
   (void)cls;
   int ticket = -1, status = OZCS_OK;
   uint64_t n = 0;
+  if ((*env)->GetArrayLength(env, ticketStatusOut) < 2) return OZCS_EINVAL;  /* before a ticket is consumed */
   const int rc = ozcs_pipe_next_completed((ozcs_pipe*)(intptr_t)pipe, block ? 1 : 0, &ticket, &status, &n);
   if (rc != OZCS_OK) return (jlong)rc;
   const jint out[2] = {ticket, status};

@@ -31,7 +31,9 @@ class OzcsVChunk(ctypes.Structure):
 
 class OzcsStats(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint64) for n in
-                ("calls", "bytes_hashed", "windows", "h2d_bytes", "d2h_bytes", "kernel_launches")]
+                ("calls", "bytes_hashed", "windows", "h2d_bytes", "d2h_bytes", "kernel_launches",
+                 # OZCS_ABI_VERSION 2
+                 "errors", "unavailable", "timed_calls", "timed_bytes", "h2d_us", "kernel_us", "d2h_us")]
 
 
 # name -> (restype, argtypes); kept in step with include/ozone_checksum.h (tests check both ways)
@@ -68,7 +70,13 @@ SIGNATURES = {
     "ozcs_pipe_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p)]),
     "ozcs_pipe_destroy": (None, [ctypes.c_void_p]),
     "ozcs_pipe_slot_bytes": (ctypes.c_uint64, [ctypes.c_void_p]),
+    "ozcs_pipe_sums_bytes": (ctypes.c_uint64, [ctypes.c_void_p]),
     "ozcs_pipe_acquire": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int)]),
+    "ozcs_pipe_acquire_wait": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int)]),
+    "ozcs_pipe_release": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "ozcs_pipe_set_in_order": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "ozcs_pipe_next_in_order": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
+                                               ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64)]),
     "ozcs_pipe_submit_slot": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint32,
                                              ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64]),
     "ozcs_pipe_submit": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64,

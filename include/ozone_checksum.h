@@ -33,7 +33,9 @@
 extern "C" {
 #endif
 
-#define OZCS_ABI_VERSION 1
+/* 2: ozcs_stats grew (timings, error counters); ozcs_pipe_release, ozcs_pipe_sums_bytes and the in-order
+ * delivery calls of the pipe were added.  Everything of version 1 is unchanged. */
+#define OZCS_ABI_VERSION 2
 
 #if defined(__GNUC__)
 #define OZCS_API __attribute__((visibility("default")))
@@ -215,10 +217,18 @@ OZCS_API uint64_t ozcs_pipe_slot_bytes(const ozcs_pipe* pipe);
  * ticket. */
 OZCS_API int ozcs_pipe_ticket_slot(int ticket);
 
+/* Capacity in bytes of the digest buffer behind every slot: a submission whose digests need more is rejected
+ * (slot_bytes / 512 + 1 digests of 32 bytes, rounded up to 256: windows of 512 bytes and more always fit).  A
+ * binding that packs several windows into one slot bounds their number with this; 0 for NULL. */
+OZCS_API uint64_t ozcs_pipe_sums_bytes(const ozcs_pipe* pipe);
+
 /* Borrow a free slot: *buf is its pinned host buffer of slot_bytes bytes for the producer to fill in place
  * (zero staging copies).  OZCS_EBUSY when no slot is free: a submitted slot stays its ticket's until that
  * ticket's tenancy has ended. */
 OZCS_API int ozcs_pipe_acquire(ozcs_pipe* pipe, void** buf, int* ticket);
+/* Hands back an acquired slot that will not be submitted (the producer failed, or found nothing to write).
+ * OZCS_EINVAL unless the ticket names an acquired, unsubmitted slot. */
+OZCS_API int ozcs_pipe_release(ozcs_pipe* pipe, int ticket);
 /* Queue copy + checksum for the first `len` bytes of an acquired slot.  sums_out (host, any memory) receives
  * the digests when the ticket completes.  A rejected submission (OZCS_EINVAL ...) releases the slot. */
 OZCS_API int ozcs_pipe_submit_slot(ozcs_pipe* pipe, int ticket, int type, uint32_t bpc, uint64_t len,
@@ -242,6 +252,30 @@ OZCS_API int ozcs_pipe_next_completed(ozcs_pipe* pipe, int block, int* ticket, i
  * them, or OZCS_OK. */
 OZCS_API int ozcs_pipe_drain(ozcs_pipe* pipe);
 
+/* ---- in-order delivery: the write path of BlockOutputStream ships chunk n before chunk n+1 ----
+ * BlockOutputStream.writeChunkToContainer (BlockOutputStream.java:645-690) copies the chunk's bytes into the
+ * request (chunk.toByteString, :648-649) and sends requests in the order the chunks were written.  A caller of
+ * that shape needs digests in submission order but does not need the pinned slot once the GPU has read it.
+ * After ozcs_pipe_set_in_order(pipe, 1) the pipe works that way: a submitted slot is released by the library
+ * the moment its digests are in sums_out -- a CRC chunk (0.1 ms) does not keep its slot while an older SHA-256 /
+ * MD5 chunk (milliseconds per 1 MiB window) is still being hashed -- and outcomes are queued and handed out
+ * strictly in submission order by ozcs_pipe_next_in_order.  In this mode ozcs_pipe_poll, ozcs_pipe_wait and
+ * ozcs_pipe_next_completed return OZCS_EINVAL (a ticket's slot may already belong to a later chunk); acquire,
+ * submit, release and drain work as before (drain waits for the GPU work; the outcomes stay queued).  At most
+ * OZCS_PIPE_ORDER_BACKLOG x n_slots outcomes may be waiting for delivery: beyond that ozcs_pipe_acquire
+ * reports OZCS_EBUSY until some have been taken.  The mode can be changed only while no ticket is outstanding
+ * and no outcome is queued (OZCS_EBUSY otherwise). */
+#define OZCS_PIPE_ORDER_BACKLOG 16
+OZCS_API int ozcs_pipe_set_in_order(ozcs_pipe* pipe, int on);
+/* The outcome of the oldest submitted ticket not yet handed out: OZCS_OK with *ticket, *status, *n_sums set once
+ * it has completed (its digests are in its sums_out); OZCS_EBUSY while it is in flight (block == 0 only; with
+ * block != 0 the call waits for it); OZCS_EEMPTY when every submitted ticket has been handed out. */
+OZCS_API int ozcs_pipe_next_in_order(ozcs_pipe* pipe, int block, int* ticket, int* status, uint64_t* n_sums);
+/* ozcs_pipe_acquire that waits for a slot instead of reporting OZCS_EBUSY, for producers that have nothing else
+ * to do meanwhile.  Still OZCS_EBUSY when waiting cannot help: every slot is held by a ticket that only its
+ * holder can end (not in-order mode: acquired, or completed and unclaimed), or the in-order backlog is full. */
+OZCS_API int ozcs_pipe_acquire_wait(ozcs_pipe* pipe, void** buf, int* ticket);
+
 /* ---- counters (no counterpart in the reference, which has no checksum-throughput metric) ---- */
 
 typedef struct ozcs_stats {
@@ -251,7 +285,21 @@ typedef struct ozcs_stats {
   uint64_t h2d_bytes;
   uint64_t d2h_bytes;
   uint64_t kernel_launches;
+  /* ---- from OZCS_ABI_VERSION 2 on ---- */
+  uint64_t errors;           /* entry-point calls that returned OZCS_EINVAL / ERANGE / EEMPTY-from-verify / EHIP /
+                                ENOMEM / ENODEV (OZCS_EBUSY and the pipe's OZCS_EEMPTY are flow control, not errors) */
+  uint64_t unavailable;      /* of those, OZCS_ENODEV / OZCS_EHIP / OZCS_ENOMEM: the calls a binding answers by
+                                falling back to its own CPU path (the library itself has none) */
+  /* Phase times of the synchronous host-pointer calls (ozcs_compute, ozcs_verify and each staged group of the
+   * batched calls), measured with HIP events on the call's own stream for one call in OZCS_STATS_SAMPLE_EVERY
+   * (the first call of a thread pool slot included), so that the events cost nothing on the others: */
+  uint64_t timed_calls;      /* calls (or groups) that were timed */
+  uint64_t timed_bytes;      /* their input bytes */
+  uint64_t h2d_us;           /* host-to-device copies, microseconds, summed over the timed calls */
+  uint64_t kernel_us;        /* kernels */
+  uint64_t d2h_us;           /* digests / verdicts back */
 } ozcs_stats;
+#define OZCS_STATS_SAMPLE_EVERY 16
 OZCS_API void ozcs_get_stats(ozcs_stats* out);
 
 #ifdef __cplusplus

@@ -16,6 +16,44 @@ from hadoop_ozone_amd import native
 MIB = 1 << 20
 
 
+def run_in_order(L, n_slots, n_chunks, mix, staged, bpc=MIB):
+    """One strictly ordered stream on an in-order pipe (ozcs_pipe_set_in_order): the producer blocks for a slot, slots go
+    back when the GPU is done with them, outcomes are taken in submission order as they become available."""
+    pipe = ctypes.c_void_p()
+    native.check(L.ozcs_pipe_create(0, n_slots, 4 * MIB, ctypes.byref(pipe)))
+    native.check(L.ozcs_pipe_set_in_order(pipe, 1))
+    src = np.random.default_rng(1).integers(0, 256, 4 * MIB, dtype=np.uint8)
+    cap = (4 * MIB // bpc) * 32
+    ring = 17 * n_slots                                   # digests of undelivered outcomes stay where they are
+    outs = [ctypes.create_string_buffer(cap) for _ in range(ring)]
+    buf, ticket, done = ctypes.c_void_p(), ctypes.c_int(), ctypes.c_int()
+    delivered = 0
+    max_backlog = 0
+    for warm in (True, False):
+        n_run = n_slots if warm else n_chunks
+        t0 = time.perf_counter()
+        submitted = delivered = 0
+        while delivered < n_run:
+            if submitted < n_run:
+                t = native.MD5 if (mix and not warm and submitted % 4 == 3) else native.CRC32
+                rc = L.ozcs_pipe_acquire_wait(pipe, ctypes.byref(buf), ctypes.byref(ticket))
+                if rc == native.OK:
+                    if staged:
+                        ctypes.memmove(buf.value, src.ctypes.data, 4 * MIB)
+                    native.check(L.ozcs_pipe_submit_slot(pipe, ticket.value, t, bpc, 4 * MIB, outs[submitted % ring], cap))
+                    submitted += 1
+                elif rc != native.EBUSY:                  # EBUSY: the backlog is full, deliver first
+                    native.check(rc)
+            block = 1 if submitted == n_run else 0
+            while L.ozcs_pipe_next_in_order(pipe, block, ctypes.byref(done), None, None) == native.OK:
+                delivered += 1
+                block = 0
+            max_backlog = max(max_backlog, submitted - delivered)
+        dt = time.perf_counter() - t0
+    L.ozcs_pipe_destroy(pipe)
+    return n_chunks * 4 * MIB / dt / 1e9, max_backlog
+
+
 def run(L, n_slots, n_chunks, mix, staged, bpc=MIB, any_order=False, only=None):
     """any_order: a full pipe is relieved by whichever ticket completes first (many streams share the pipe, or the
     stream ships chunks as their digests arrive) instead of by the oldest ticket (one strictly ordered stream)."""
@@ -100,6 +138,21 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "mix-in-order":   # one stream that ships its chunks in order: CRC32:MD5 3:1 at 1 MiB windows
         for slots in (128, 256, 512):
             print(json.dumps({"slots": slots, "oldest_first_GBps": round(run(L, slots, 4096, True, False, MIB, False), 2)}), flush=True)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "in-order":   # the in-order pipe against waiting for the oldest ticket
+        for staged in (False, True):
+            for slots in (32, 64, 128, 256):
+                g, backlog = run_in_order(L, slots, 4096, True, staged, MIB)
+                print(json.dumps({"types": "CRC32:MD5 3:1", "bytes_per_checksum": MIB, "slots": slots,
+                                  "input": "memcpy from pageable memory into the slot" if staged else "produced in the pinned slot",
+                                  "harvest": "in-order pipe (slots recycled on completion, outcomes in submission order)",
+                                  "GBps": round(g, 2), "most_outcomes_pending": backlog}), flush=True)
+        for slots in (64, 128, 256):
+            print(json.dumps({"types": "CRC32:MD5 3:1", "bytes_per_checksum": MIB, "slots": slots,
+                              "harvest": "oldest ticket first (slot held until its ticket is waited for)",
+                              "GBps": round(run(L, slots, 4096, True, False, MIB, False), 2)}), flush=True)
+        g, backlog = run_in_order(L, 64, 4096, False, False, MIB)
+        print(json.dumps({"types": "CRC32", "slots": 64, "harvest": "in-order pipe", "GBps": round(g, 2)}), flush=True)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "mix":   # quick look: CRC32:MD5 3:1 at 1 MiB windows only
         for slots in (64, 128):

@@ -4,7 +4,11 @@
  * (ctypes), so that its own logic -- argument checks, the heap-array path through its pinned pipe, the malloc'd
  * path, direct buffers, the pipe wrappers, the error mapping -- runs on the GPU through the C ABI.  A Java array
  * or direct buffer is a small record here (kind, storage, length); region calls outside an array raise the
- * pending-exception flag as ArrayIndexOutOfBoundsException would.  Nothing of this reaches a real JVM.
+ * pending-exception flag as ArrayIndexOutOfBoundsException would.  Local references are counted the way a JVM
+ * under -Xcheck:jni would: GetObjectArrayElement and NewDirectByteBuffer create one, DeleteLocalRef gives one
+ * back, and a native frame that holds more than the 16 the JNI specification guarantees (no EnsureLocalCapacity
+ * here) raises the pending-exception flag; the Python side opens a frame before each native call.  Nothing of
+ * this reaches a real JVM.
  */
 #include <jni.h>
 #include <stdlib.h>
@@ -18,6 +22,12 @@ struct _jobject {
 };
 
 static __thread int t_pending; /* an exception is pending on this thread */
+static __thread int t_local_refs, t_local_refs_peak; /* live local references of the current native frame */
+enum { kGuaranteedLocalRefs = 16 };
+static void new_local_ref(void) {
+  if (++t_local_refs > t_local_refs_peak) t_local_refs_peak = t_local_refs;
+  if (t_local_refs > kGuaranteedLocalRefs) t_pending = 1;
+}
 
 static jsize GetArrayLength(JNIEnv* env, jarray a) { (void)env; return (jsize)a->len; }
 static int region_ok(jarray a, int kind, jsize start, jsize len) {
@@ -45,6 +55,7 @@ static jobject NewDirectByteBuffer(JNIEnv* env, void* address, jlong capacity) {
   o->kind = kDirectBuffer;
   o->ptr = address;
   o->len = (long)capacity;
+  new_local_ref();
   return o;
 }
 static void* GetDirectBufferAddress(JNIEnv* env, jobject b) { (void)env; return b && b->kind == kDirectBuffer ? b->ptr : NULL; }
@@ -56,7 +67,12 @@ static jobject GetObjectArrayElement(JNIEnv* env, jobjectArray a, jsize index) {
     t_pending = 1;
     return NULL;
   }
+  if (((jobject*)a->ptr)[index]) new_local_ref();
   return ((jobject*)a->ptr)[index];
+}
+static void DeleteLocalRef(JNIEnv* env, jobject ref) {
+  (void)env;
+  if (ref) t_local_refs--;
 }
 static void GetIntArrayRegion(JNIEnv* env, jintArray a, jsize start, jsize len, jint* buf) {
   (void)env;
@@ -66,7 +82,7 @@ static void GetIntArrayRegion(JNIEnv* env, jintArray a, jsize start, jsize len, 
 static const struct JNINativeInterface_ g_table = {
     GetArrayLength, GetByteArrayRegion, SetByteArrayRegion, SetIntArrayRegion,
     ExceptionCheck, NewDirectByteBuffer, GetDirectBufferAddress, GetDirectBufferCapacity,
-    GetObjectArrayElement, GetIntArrayRegion,
+    GetObjectArrayElement, GetIntArrayRegion, DeleteLocalRef,
 };
 static JNIEnv g_env = &g_table;
 
@@ -83,6 +99,13 @@ JNIEXPORT jobject fake_object(int kind, void* storage, long len) {
 JNIEXPORT void fake_release(jobject o) { free(o); }
 JNIEXPORT void* fake_storage(jobject o) { return o ? o->ptr : NULL; }
 JNIEXPORT long fake_length(jobject o) { return o ? o->len : -1; }
+/* A native method is entered with an empty local frame; returns the previous frame's peak. */
+JNIEXPORT int fake_new_frame(void) {
+  const int peak = t_local_refs_peak;
+  t_local_refs = t_local_refs_peak = 0;
+  return peak;
+}
+JNIEXPORT int fake_local_refs_peak(void) { return t_local_refs_peak; }
 JNIEXPORT int fake_exception_pending(int clear) {
   const int p = t_pending;
   if (clear) t_pending = 0;

@@ -40,5 +40,6 @@ struct JNINativeInterface_ {
   jlong (*GetDirectBufferCapacity)(JNIEnv* env, jobject buf);
   jobject (*GetObjectArrayElement)(JNIEnv* env, jobjectArray array, jsize index);
   void (*GetIntArrayRegion)(JNIEnv* env, jintArray array, jsize start, jsize len, jint* buf);
+  void (*DeleteLocalRef)(JNIEnv* env, jobject ref);
 };
 #endif

@@ -40,7 +40,7 @@ def test_exports_only_the_abi():
 
 def test_pure_queries():
     L = native.lib()
-    assert L.ozcs_abi_version() == 1
+    assert L.ozcs_abi_version() == 2
     assert [L.ozcs_digest_size(t) for t in (0, 1, 2, 3, 4, 5, 6)] == [0, 0, 4, 4, 32, 16, 0]
     assert L.ozcs_num_checksums(55, 10) == 6          # TestChecksum.java:47-62
     assert L.ozcs_num_checksums(100, 20) == 5
@@ -81,3 +81,33 @@ def test_no_gpu_fails_loudly_instead_of_falling_back():
     assert L.ozcs_compute(native.CRC32, 16, b"abc", 3, out, 64, ctypes.byref(n)) == native.ENODEV
     with pytest.raises(native.OzcsError):
         native.compute(native.CRC32, 16, b"abc")
+
+
+def test_stats_count_errors_and_unavailable_calls():
+    # ABI 2: every entry point's negative outcome is counted; ENODEV / EHIP / ENOMEM also as "unavailable" (the calls a
+    # binding answers with its own CPU path).  OZCS_EBUSY is flow control and not counted.
+    import torch
+    L = native.lib()
+    before = native.stats()
+    out = ctypes.create_string_buffer(64)
+    n = ctypes.c_uint64(0)
+    assert L.ozcs_compute(9, 16, b"abc", 3, out, 64, ctypes.byref(n)) == native.EINVAL
+    assert L.ozcs_pipe_release(None, 0) == native.EINVAL
+    fm = ctypes.c_int64(0)
+    assert L.ozcs_verify(native.CRC32, 16, b"abc", 3, b"", 0, 0, ctypes.byref(fm)) == native.EEMPTY
+    after = native.stats()
+    assert after["errors"] - before["errors"] == 3
+    assert after["unavailable"] == before["unavailable"]
+    if not torch.cuda.is_available():
+        assert L.ozcs_compute(native.CRC32, 16, b"abc", 3, out, 64, ctypes.byref(n)) == native.ENODEV
+        last = native.stats()
+        assert last["errors"] - after["errors"] == 1 and last["unavailable"] - after["unavailable"] == 1
+        assert last["timed_calls"] == 0 and last["kernel_us"] == 0
+
+
+def test_test_hooks_are_not_in_the_product_library():
+    # the two environment hooks exist only in libozcs_testhooks.so (-DOZCS_TEST_HOOKS)
+    product = open(native.LIB_PATH, "rb").read()
+    hooks = open(os.path.join(native.CSRC, "libozcs_testhooks.so"), "rb").read()
+    for name in (b"OZCS_TEST_REPLICATE_DEVICES", b"OZCS_FAULT_PIPE_DIGEST_LAUNCH"):
+        assert name not in product and name in hooks

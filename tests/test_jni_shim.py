@@ -84,12 +84,21 @@ class FakeJvm:
                "calculateWindowSumsDirect": (J, [I, I, V, I, I, V, V, V]),
                "pipeCreate": (J, [I, I, J]), "pipeDestroy": (None, [J]), "pipeAcquire": (V, [J, V]),
                "pipeSubmit": (I, [J, I, I, I, J, V]), "pipeWait": (J, [J, I]),
-               "pipeNextCompleted": (J, [J, B, V]), "pipeTicketSlot": (I, [I])}
+               "pipeNextCompleted": (J, [J, B, V]), "pipeTicketSlot": (I, [I]),
+               "pipeRelease": (I, [J, I]), "pipeSlotBytes": (J, [J]), "pipeSumsBytes": (J, [J]),
+               "pipeSetInOrder": (I, [J, B]), "pipeNextInOrder": (J, [J, B, V]), "pipeAcquireWait": (V, [J, V])}
+        self.peak_local_refs = 0       # most local references any native call held at once
         for name, (ret, args) in sig.items():
             f = getattr(L, PFX + name)
             f.restype = ret
             f.argtypes = [V, V] + args
-            setattr(self, name, (lambda f: lambda *a: f(self.env, None, *a))(f))
+            setattr(self, name, (lambda f: lambda *a: self._call(f, *a))(f))
+
+    def _call(self, f, *a):
+        self.lib.fake_new_frame()      # a native method starts with an empty local reference frame
+        r = f(self.env, None, *a)
+        self.peak_local_refs = max(self.peak_local_refs, self.lib.fake_local_refs_peak())
+        return r
 
     def obj(self, kind, arr):
         self.keep.append(arr)
@@ -229,3 +238,199 @@ def test_shim_one_window_per_buffer_in_one_call(jvm):
     sums = np.zeros(64, dtype=np.uint8)
     assert jvm.calculateWindowSumsDirect(bpc, oracle.CRC32, jvm.obj(K_DIRECT, sums), 0, 64, jvm.obj(K_OBJECTS, objs),
                                          jvm.obj(K_INTS, pos), jvm.obj(K_INTS, lim)) == -1
+    assert not jvm.pending()
+
+
+@pytest.mark.gpu
+def test_shim_256_windows_stay_within_the_guaranteed_local_references(jvm):
+    # a 4 MiB chunk at 16 KiB windows handed over as 256 buffers: every GetObjectArrayElement creates a local
+    # reference and a native frame is guaranteed only 16 -- the stand-in table counts them like -Xcheck:jni
+    import oracle
+    bpc, n = 16384, 256
+    bufs = [oracle.splitmix64(7000 + i, bpc) for i in range(n)]
+    objs = np.array([jvm.obj(K_DIRECT, b) for b in bufs], dtype=np.uint64)
+    pos = np.zeros(n, dtype=np.int32)
+    lim = np.full(n, bpc, dtype=np.int32)
+    sums = np.zeros(4 * n, dtype=np.uint8)
+    jvm.peak_local_refs = 0
+    got = jvm.calculateWindowSumsDirect(bpc, oracle.CRC32, jvm.obj(K_DIRECT, sums), 0, sums.size,
+                                        jvm.obj(K_OBJECTS, objs), jvm.obj(K_INTS, pos), jvm.obj(K_INTS, lim))
+    assert got == n and not jvm.pending() and jvm.peak_local_refs <= 2
+    assert bytes(sums) == b"".join(oracle.compute(oracle.CRC32, bpc, b) for b in bufs)
+    # the stand-in does notice a frame that keeps them: 17 live references raise its pending-exception flag
+    jvm.lib.fake_new_frame()
+    GetObjectArrayElement = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32)
+    table = ctypes.cast(ctypes.cast(jvm.env, ctypes.POINTER(ctypes.c_void_p))[0], ctypes.POINTER(ctypes.c_void_p))
+    get = GetObjectArrayElement(table[8])
+    arr = jvm.obj(K_OBJECTS, objs)
+    for i in range(17):
+        get(jvm.env, arr, i)
+    assert jvm.lib.fake_local_refs_peak() == 17 and jvm.pending()
+
+
+# ---- the Java class's routing, executed: tests/java_side.py restates GpuChecksum.computeWindows ----
+
+@pytest.fixture()
+def java(jvm):
+    from java_side import JavaSide
+    j = JavaSide(jvm, pipe_slots=4, pipe_slot_bytes=2 << 20)     # small, so that a 12 MiB input recycles its own slots
+    yield j
+    j.close()
+
+
+def _windows_of(buf, bpc):
+    # ChunkBufferImplWithByteBuffer.iterate (ChunkBufferImplWithByteBuffer.java:62-83): duplicates cut every bpc bytes
+    out = []
+    p = buf.pos
+    while p < buf.lim:
+        d = buf.duplicate()
+        d.pos, d.lim = p, min(p + bpc, buf.lim)
+        out.append(d)
+        p = d.lim
+    return out
+
+
+@pytest.mark.gpu
+def test_java_side_read_only_heap_buffers_reach_the_gpu_through_pinned_slots(jvm, java):
+    # Checksum.computeChecksum(byte[]) / (ByteBuffer) make their argument read-only first (Checksum.java:142-145):
+    # such a buffer has neither array() nor an address, so its windows are put() into pinned pipe slots
+    import oracle
+    from java_side import JBuffer
+    for t, n, bpc, off in ((oracle.CRC32, 4 << 20, 1 << 20, 0), (oracle.CRC32C, 12 << 20, 16384, 5),
+                           (oracle.CRC32, 55, 10, 0), (oracle.SHA256, 3072, 2048, 1), (oracle.MD5, 300000, 65536, 3),
+                           (oracle.CRC32, (2 << 20) + 1, 1 << 20, 0)):
+        heap = oracle.splitmix64(n + t, n + off + 9)
+        buf = JBuffer(heap, off, off + n, direct=False, read_only=True)
+        windows = _windows_of(buf, bpc)
+        out = []
+        java.calls.clear()
+        jvm.peak_local_refs = 0
+        assert java.computeWindows(t, bpc, windows, out)
+        assert b"".join(out) == oracle.compute(t, bpc, heap[off:off + n]), (t, n, bpc)
+        assert "pipeSubmit" in java.calls and "calculateWindowSumsDirect" not in java.calls
+        assert not jvm.pending() and jvm.peak_local_refs <= 1
+        # a read-only window has no array: ChecksumByteBufferImpl.update and MessageDigest.update consume it
+        assert all(w.pos == w.lim for w in windows)
+    # a writable heap buffer (BlockOutputStream's chunk buffer): same route; CRC leaves it unconsumed, a digest consumes
+    heap = oracle.splitmix64(99, 1 << 20)
+    for t, consumed in ((oracle.CRC32C, False), (oracle.MD5, True)):
+        windows = _windows_of(JBuffer(heap), 1 << 18)
+        out = []
+        assert java.computeWindows(t, 1 << 18, windows, out)
+        assert b"".join(out) == oracle.compute(t, 1 << 18, heap)
+        assert all((w.pos == w.lim) == consumed for w in windows)
+
+
+@pytest.mark.gpu
+def test_java_side_lists_of_windows_ragged_and_direct(jvm, java):
+    import oracle
+    from java_side import JBuffer
+    bpc = 4096
+    # one ByteString per window (Checksum.java:282-288), read-only; a short element in the middle ends its slot's group,
+    # an element longer than bpc contributes its first bpc bytes only (Checksum.java:186-198)
+    lens = [4096, 4096, 100, 4096, 9000, 1, 4096]
+    bufs = [oracle.splitmix64(600 + i, n + 8) for i, n in enumerate(lens)]
+    windows = [JBuffer(b, 4, 4 + n, read_only=True) for b, n in zip(bufs, lens)]
+    for t in (oracle.CRC32, oracle.SHA256):
+        ws = [w.duplicate() for w in windows]
+        out = []
+        java.calls.clear()
+        assert java.computeWindows(t, bpc, ws, out)
+        assert out == [oracle.compute(t, bpc, b[4:4 + min(n, bpc)]) for b, n in zip(bufs, lens)]
+        assert java.calls.count("pipeSubmit") == 3        # groups: [w0 w1 w2] [w3 w4 w5] [w6]: a short window ends its group
+        assert [w.pos - 4 for w in ws] == [min(n, bpc) for n in lens]
+    # direct buffers: in place, one native call; slices of one direct buffer are recognised as one chunk
+    direct = oracle.splitmix64(41, 10 * bpc + 77)
+    ws = _windows_of(JBuffer(direct, 3, direct.size, direct=True, read_only=True), bpc)
+    out = []
+    java.calls.clear()
+    before = _stats()
+    assert java.computeWindows(oracle.CRC32C, bpc, ws, out)
+    assert b"".join(out) == oracle.compute(oracle.CRC32C, bpc, direct[3:])
+    assert java.calls == ["calculateWindowSumsDirect"] and all(w.pos == w.lim for w in ws)
+    after = _stats()
+    assert after["kernel_launches"] - before["kernel_launches"] == 1      # ozcs_compute over the whole range
+    # mixed direct and heap windows: everything is staged
+    ws = [JBuffer(direct, 0, bpc, direct=True), JBuffer(bufs[0], 0, bpc)]
+    out = []
+    java.calls.clear()
+    assert java.computeWindows(oracle.CRC32, bpc, ws, out) and "pipeSubmit" in java.calls
+    assert out == [oracle.compute(oracle.CRC32, bpc, direct[:bpc]), oracle.compute(oracle.CRC32, bpc, bufs[0][:bpc])]
+
+
+@pytest.mark.gpu
+def test_java_side_declines_without_touching_anything(jvm, java):
+    import oracle
+    from java_side import JBuffer
+    big = oracle.splitmix64(5, (2 << 20) + 4096)
+    # a window larger than a pipe slot (bpc 4 MiB against 2 MiB slots): the Java engines keep the call
+    ws = _windows_of(JBuffer(big, read_only=True), 4 << 20)
+    out = []
+    assert not java.computeWindows(oracle.CRC32, 4 << 20, ws, out) and out == [] and ws[0].pos == 0
+    # an empty window (a consumed buffer of an IncrementalChunkBuffer): declined as well
+    ws = [JBuffer(big, 0, 4096, read_only=True), JBuffer(big, 10, 10, read_only=True)]
+    assert not java.computeWindows(oracle.CRC32, 4096, ws, out) and out == []
+    # every slot held by other threads: declined, and the slots it did get are given back
+    pipe = java._sharedPipe()
+    held = []
+    for _ in range(4):
+        tk = np.zeros(1, dtype=np.int32)
+        assert jvm.pipeAcquire(pipe, jvm.obj(K_INTS, tk))
+        held.append(int(tk[0]))
+    ws = _windows_of(JBuffer(big, 0, 1 << 20, read_only=True), 1 << 18)
+    assert not java.computeWindows(oracle.CRC32, 1 << 18, ws, out) and out == [] and all(w.pos != w.lim for w in ws)
+    for tk in held:
+        assert jvm.pipeRelease(pipe, tk) == 0
+    assert jvm.pipeRelease(pipe, held[0]) == -1          # released already
+    assert java.computeWindows(oracle.CRC32, 1 << 18, ws, out)
+    assert b"".join(out) == oracle.compute(oracle.CRC32, 1 << 18, big[:1 << 20])
+    assert not jvm.pending()
+
+
+def _stats():
+    from hadoop_ozone_amd import native
+    return native.stats()
+
+
+def test_checksum_java_patch_applies_to_the_reference():
+    # the reference-side change ships as a minimal-context diff; it must apply to the reference's own Checksum.java
+    import shutil
+    import tempfile
+    rel = "hadoop-hdds/common/src/main/java/org/apache/hadoop/ozone/common/Checksum.java"
+    ref = os.path.join("/root/reference", rel)
+    if not os.path.exists(ref) or not shutil.which("patch"):
+        pytest.skip("the reference tree (or patch) is not on this machine")
+    patch = os.path.join(ROOT, "hadoop-ozone_amd", "jni", "Checksum.java.patch")
+    with tempfile.TemporaryDirectory() as tmp:
+        dst = os.path.join(tmp, rel)
+        os.makedirs(os.path.dirname(dst))
+        shutil.copy(ref, dst)
+        r = subprocess.run(["patch", "-p1", "--dry-run", "-i", patch], cwd=tmp, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        r = subprocess.run(["patch", "-p1", "-i", patch], cwd=tmp, capture_output=True, text=True)
+        assert r.returncode == 0 and "fuzz" not in r.stdout, r.stdout + r.stderr
+        text = open(dst).read()
+    # the one seam every overload funnels through (Checksum.java:119-153, 210-290 all end in computeChecksum(ChunkBuffer))
+    assert text.count("GpuChecksum.computeWindows(checksumType, bytesPerChecksum, windows") == 1
+    assert text.count("{") == text.count("}") and text.count("(") == text.count(")")
+    body = text[text.index("public ChecksumData computeChecksum(ChunkBuffer data)"):]
+    assert body.index("data.iterate(bytesPerChecksum)") < body.index("if (!GpuChecksum.computeWindows(") < \
+        body.index("checksumList.add(computeChecksum(b, function, bytesPerChecksum))")
+
+
+def test_java_class_is_plausible_java():
+    # no JDK here: at least brackets balance outside comments and strings, every statement-level line ends properly,
+    # and the method the patch calls exists with the argument list the patch passes
+    java = open(JAVA).read()
+    code = re.sub(r"/\*.*?\*/", "", java, flags=re.S)
+    code = re.sub(r"//[^\n]*", "", code)
+    code = re.sub(r'"(?:[^"\\]|\\.)*"', '""', code)
+    for a, b in ("{}", "()", "[]"):
+        assert code.count(a) == code.count(b), (a, code.count(a), code.count(b))
+    assert re.search(r"public static boolean computeWindows\(ChecksumType checksumType, int bytesPerSum,\s*"
+                     r"List<ByteBuffer> windows,\s*List<ByteString> out\)", code)
+    for line in code.splitlines():
+        t = line.strip()
+        if not t or t.startswith(("@", "case ", "default:", "*")):
+            continue
+        assert t[-1] in "{};,(:|&?+=" or t.endswith(("&&", "||")) or t[-1] == ")" , line
