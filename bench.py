@@ -24,9 +24,7 @@ MIB = 1 << 20
 BLOCK_BYTES = 256 * MIB   # ozone.scm.block.size, OzoneConfigKeys.java:115-116
 CHUNK_BYTES = 4 * MIB     # ozone.scm.chunk.size / stream buffer, OzoneClientConfig.java:50-55
 HBM_PEAK_GBPS = 8000.0    # MI355X HBM3E datasheet peak
-# Recorded constant, not measured in this run: a pure non-temporal streaming read in the CRC kernel's access
-# pattern on MI355X (tools/hbm_read_bench.hip).
-RECORDED_NT_READ = {"GBps": 7070.0, "source": "profiles/r01_hbm_read_microbench.log", "measured_in_this_run": False}
+CHECK_WINDOWS = 48        # digests of the timed run compared with the CPU oracle afterwards (first, last, random)
 # Integer-VALU ceiling of the chip for SHA-256 / MD5: 256 CUs x 4 SIMDs, one wave64 vector instruction per
 # 4 cycles per SIMD, at the 2.4 GHz maximum clock.
 SIMDS = 256 * 4
@@ -82,6 +80,53 @@ def self_launch(args):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     r = subprocess.run(cmd, env=env)
     sys.exit(r.returncode)
+
+
+def nt_read_ceiling(gib):
+    """A bare non-temporal read of `gib` GiB in the 1 MiB-window CRC kernel's own access pattern (G wavefronts per
+    window, two 1 KiB rows each, one stripe ahead; tools/hbm_read_bench.hip, mode "crc"), measured on this box by a
+    CHILD process that has finished before this process touches the GPU.  What the memory system delivers to that
+    address stream with no arithmetic at all: the kernel cannot be faster than the best of these patterns."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "hbm_read_bench")
+    if not os.path.exists(exe):
+        return {"measured_in_this_run": False, "note": "tools/hbm_read_bench is not built (make -C tools)"}
+    try:
+        r = subprocess.run([exe, str(gib), "crc"], capture_output=True, text=True, timeout=120)
+    except (OSError, subprocess.SubprocessError) as e:
+        return {"measured_in_this_run": False, "note": "tools/hbm_read_bench did not run: %r" % (e,)}
+    pats = {}
+    for m in re.finditer(r"crc pattern G=(\d+).*?avg\s+([\d.]+) GB/s\s+best\s+([\d.]+) GB/s", r.stdout):
+        pats["G=%s" % m.group(1)] = {"avg_GBps": float(m.group(2)), "best_GBps": float(m.group(3))}
+    if r.returncode != 0 or not pats:
+        return {"measured_in_this_run": False, "note": "tools/hbm_read_bench failed (rc %d): %s" % (r.returncode, (r.stdout + r.stderr)[-200:])}
+    top = max(pats, key=lambda k: pats[k]["avg_GBps"])
+    return {"GBps": pats[top]["avg_GBps"], "pattern": "wavefronts per window " + top, "patterns": pats, "buffer_GiB": gib,
+            "source": "tools/hbm_read_bench %d crc, child process, 10 launches after 3 warm-ups per pattern" % gib,
+            "measured_in_this_run": True}
+
+
+def check_against_oracle(type_id, bpc, data, sums, n_windows, ds, seed=7):
+    """After the timed loop: CHECK_WINDOWS windows of the batch (the first, the last, the rest at random) are copied to
+    the host and their digests, as the timed launches left them in `sums`, compared with the CPU oracle.  The oracle
+    is the checker here, never the thing measured."""
+    import random
+    import oracle
+    wpc = (CHUNK_BYTES + bpc - 1) // bpc
+    rng = random.Random(seed)
+    picks = sorted({0, n_windows - 1} | {rng.randrange(n_windows) for _ in range(CHECK_WINDOWS - 2)})
+    got = sums.cpu().numpy()
+    bad = []
+    for g in picks:
+        c, i = divmod(g, wpc)
+        lo = c * CHUNK_BYTES + i * bpc
+        hi = min(lo + bpc, (c + 1) * CHUNK_BYTES)
+        want = oracle.compute(type_id, bpc, data[lo:hi].cpu().numpy())
+        if bytes(got[g * ds:(g + 1) * ds]) != want:
+            bad.append(g)
+    return {"windows": len(picks), "ok": not bad, "against": "CPU oracle (oracle/ozcs_oracle.c)",
+            **({"mismatching_windows": bad[:8]} if bad else {})}
 
 
 CPU_PASSES = 40  # passes of the headline CPU baseline: the host cores are shared, the best pass is reported
@@ -178,6 +223,8 @@ def main():
     ap.add_argument("--bpc", type=int, default=MIB)
     ap.add_argument("--mode", default="compute", choices=["compute", "verify"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ceiling", action="store_true", help="skip the bare-read measurement by tools/hbm_read_bench")
+    ap.add_argument("--no-check", action="store_true", help="skip the comparison of sampled digests with the CPU oracle")
     ap.add_argument("--zeros", action="store_true", help="all-zero data instead of random bytes (the rate must not depend on the data)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --device-index 0 rehearses the multi-rank path on a one-GPU box")
@@ -186,6 +233,12 @@ def main():
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_launch(args)
+
+    # the bare-read ceiling of this box, by a child process, before this process touches the GPU (one GPU only: the
+    # child would otherwise compete with the other ranks)
+    ceiling = None
+    if args.gpus == 1 and args.type in ("CRC32", "CRC32C") and not args.no_ceiling:
+        ceiling = nt_read_ceiling(min(16, max(1, args.blocks // 4)))
 
     import torch
     import torch.distributed as dist
@@ -267,6 +320,19 @@ def main():
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
     avg_kernel_s = sum(kernel_ms) / len(kernel_ms) / 1e3
 
+    # ---- outside the timed region: the digests the timed launches produced (verify: checked against) are proven on a
+    # sample; a mismatch fails the run
+    check = None
+    if not args.no_check:
+        check = check_against_oracle(type_id, args.bpc, data, sums, n_windows, ds, seed=7 + rank)
+        if args.mode == "verify":
+            check["verdicts_all_clean"] = bool(int(first_mismatch.max()) == -1 and int(first_mismatch.min()) == -1)
+            check["ok"] = check["ok"] and check["verdicts_all_clean"]
+        if not check["ok"]:
+            print(json.dumps({"error": "digests of the benchmarked launches differ from the oracle", "rank": rank, "check": check}),
+                  file=sys.stderr, flush=True)
+            sys.exit(3)
+
     if rank == 0:
         value = aggregate(nbytes, args.steps, elapsed, world)
         # per launch: window bytes read + digest bytes written (verify: read, plus one verdict word per chunk)
@@ -291,9 +357,14 @@ def main():
                          "traffic": prof.get("hbm_bytes_per_launch") if prof else None,
                          "kernel_ms_avg": round(avg_kernel_s * 1e3, 4), "kernel_ms_min": round(min(kernel_ms), 4),
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "kernel_source_hash": src_hash,
-                         "recorded_nt_read_ceiling": RECORDED_NT_READ},
+                         "kernel_source_hash": src_hash},
         }
+        if ceiling is not None:
+            out["roofline"]["nt_read_ceiling"] = ceiling
+            if ceiling.get("measured_in_this_run"):
+                out["roofline"]["frac_of_nt_read_ceiling"] = round(achieved / ceiling["GBps"], 4)
+        if check is not None:
+            out["check"] = check
         if prof_note:
             out["roofline"]["traffic_note"] = prof_note
         # whole job against the HBM of all GPUs that took part (host-timed, launch gaps included); the per-kernel

@@ -368,13 +368,16 @@ class Checksum:
         """Checksum.java:62-64: Guava Ints.toByteArray -> 4 bytes big-endian."""
         return (n & 0xFFFFFFFF).to_bytes(4, "big")
 
-    def computeChecksum(self, data, off=None, length=None, reference_list_quirk=False):
+    def computeChecksum(self, data, off=None, length=None, reference_list_quirk=True):
         """The five computeChecksum overloads (Checksum.java:119-177).
 
-        reference_list_quirk (list inputs only): False, the default, checksums every element of the list -- the
-        documented intent (Checksum.java:279-281) and what a Checksum patched to call this library yields, since
-        the patch hands all buffers of the list to one native call.  True reproduces the unpatched reference
-        bit for bit: only the elements reference_list_windows() names are checksummed (three of four, 24 of 256).
+        reference_list_quirk (list inputs only): True, the default, is the reference bit for bit -- the list
+        overload wraps the list in a ChunkBuffer (Checksum.java:148-153) whose iterator stops early on lists of
+        four or more elements, so only the elements reference_list_windows() names are checksummed (three of four,
+        24 of 256).  It is the same default as ChunkBuffer.wrap(list), so computeChecksum(list) ==
+        computeChecksum(ChunkBuffer.wrap(list)) as in the reference, and what a Checksum patched to call this
+        library yields (the patch keeps the reference's iteration and only moves the per-window function to the
+        GPU).  False checksums every element: the documented intent (Checksum.java:279-281).
 
         data: bytes-like (byte[] / ByteBuffer overloads; off/length as in computeChecksum(byte[],int,int)),
         a chunk_buffer.ByteBuffer or ChunkBuffer (windows as its iterate(bytesPerChecksum) cuts them),
@@ -458,7 +461,7 @@ class Checksum:
         return [o.raw for o in outs]
 
     @staticmethod
-    def verifyChecksum(data, checksumData, startIndex=0, isSingleByteString=None, reference_list_quirk=False):
+    def verifyChecksum(data, checksumData, startIndex=0, isSingleByteString=None, reference_list_quirk=True):
         """The three verifyChecksum overloads (Checksum.java:210-290).
 
         reference_list_quirk: as in computeChecksum, for the one-element-per-window layout (:282-288).

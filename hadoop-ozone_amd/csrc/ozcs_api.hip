@@ -66,12 +66,14 @@ int tally(int rc, bool empty_is_flow) {
   return rc;
 }
 
-// ---- phase timing of the host-pointer calls, one call in OZCS_STATS_SAMPLE_EVERY per pooled context ----
+// ---- phase timing of the host-pointer calls, one call in OZCS_STATS_SAMPLE_EVERY ----
 // Four events on the call's stream: before the copies in, after them, after the kernels, after the copy back.
-// The first call of a context is timed (so that a process that makes a handful of calls has figures at all),
-// then every OZCS_STATS_SAMPLE_EVERY-th.  Events are created on first use and live with the context.
+// The first call of the process is timed (so that a process that makes a handful of calls has figures at all),
+// then every OZCS_STATS_SAMPLE_EVERY-th, counted over all threads.  Events are created on first use and live with
+// the pooled context.
+static std::atomic<uint64_t> s_phase_seq{0};
 PhaseTimer::PhaseTimer(HostCtx* c, uint64_t bytes) : c_(c), bytes_(bytes), on_(false) {
-  if (c->calls++ % OZCS_STATS_SAMPLE_EVERY != 0) return;
+  if (s_phase_seq.fetch_add(1, std::memory_order_relaxed) % OZCS_STATS_SAMPLE_EVERY != 0) return;
   for (hipEvent_t& ev : c->phase)
     if (!ev && hipEventCreate(&ev) != hipSuccess) {
       ev = nullptr;

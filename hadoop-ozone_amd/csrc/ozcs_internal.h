@@ -33,9 +33,8 @@ struct HostCtx {
   size_t h_stage_cap = 0;
   void* h_sums = nullptr;
   size_t h_sums_cap = 0;
-  // phase timing of sampled calls (PhaseTimer): events created on first use, and how many calls the context served
+  // phase timing of sampled calls (PhaseTimer): events created on first use
   hipEvent_t phase[4] = {nullptr, nullptr, nullptr, nullptr};
-  uint64_t calls = 0;
 };
 
 // Times the three phases of a host-pointer call (copies in, kernels, copy back) with events on the context's

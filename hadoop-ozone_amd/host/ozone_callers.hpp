@@ -165,14 +165,34 @@ struct ScrubChunk {
 
 namespace detail {
 
+inline bool fileExists(const std::string& path) {
+  FILE* f = std::fopen(path.c_str(), "rb");
+  if (f) std::fclose(f);
+  return f != nullptr;
+}
+
 // All chunks (each with the id of its block) read and hashed by ONE ozcs_verify_batch call; then the reference's
-// order of events replayed chunk by chunk.
+// order of events replayed chunk by chunk.  The per-chunk gate of scanData (KeyValueContainerCheck.java:241-256)
+// comes first: a chunk whose file does not exist is not read -- at its turn in the replay the block is looked up
+// again (blockStillExists; the reference asks the block table, :243-247) and IOException("Missing chunk file
+// <path>") is thrown if it is still there, else the chunk is passed over; a chunk whose stored checksum type is
+// NONE is passed over too: not read, not throttled, not judged (:252-253).
 inline long long verifyChunks(const std::vector<std::pair<std::string, const ScrubChunk*>>& flat, ChunkLayOutVersion layout,
-                              const std::function<void(long long)>& throttler) {
+                              const std::function<void(long long)>& throttler,
+                              const std::function<bool(const std::string&)>& blockStillExists = {}) {
+  enum Gate : char { kVerify, kMissing, kSkipped };
   std::vector<std::string> reads, stored;
+  std::vector<Gate> gate;
   std::vector<ozcs_vchunk> v(flat.size());
   for (const auto& bc : flat) {
     const ScrubChunk& c = *bc.second;
+    gate.push_back(!fileExists(c.chunkFile) ? kMissing
+                   : c.checksumData.getChecksumType() == ChecksumType::NONE ? kSkipped : kVerify);
+    if (gate.back() != kVerify) {
+      reads.emplace_back();
+      stored.emplace_back();
+      continue;
+    }
     reads.push_back(readChunkWindows(c.chunkOffset, c.chunkLen, c.checksumData, c.chunkFile, layout));
     const long long bpc = c.checksumData.getBytesPerChecksum();
     const long long nwin = bpc ? ((long long)reads.back().size() + bpc - 1) / bpc : 0;
@@ -185,8 +205,8 @@ inline long long verifyChunks(const std::vector<std::pair<std::string, const Scr
     const long long bpc = c.checksumData.getBytesPerChecksum();
     const uint64_t nwin = bpc ? (reads[i].size() + (size_t)bpc - 1) / (size_t)bpc : 0;
     v[i] = ozcs_vchunk{};
-    v[i].type = nwin ? (int)c.checksumData.getChecksumType() : OZCS_NONE;  // nothing read: only the length check applies
-    v[i].bpc = (uint32_t)bpc;
+    v[i].type = nwin && gate[i] == kVerify ? (int)c.checksumData.getChecksumType() : OZCS_NONE;  // nothing read: only the length check applies
+    v[i].bpc = gate[i] == kVerify ? (uint32_t)bpc : 1u;
     v[i].data = reads[i].empty() ? nullptr : reads[i].data();
     v[i].len = reads[i].size();
     v[i].expected = stored[i].data();
@@ -196,6 +216,11 @@ inline long long verifyChunks(const std::vector<std::pair<std::string, const Scr
   long long total = 0;
   for (size_t i = 0; i < flat.size(); i++) {
     const ScrubChunk& c = *flat[i].second;
+    if (gate[i] == kSkipped) continue;  // :252-253
+    if (gate[i] == kMissing) {          // "concurrent mutation in Block DB? lookup the block again" (:242-251)
+      if (!blockStillExists || blockStillExists(flat[i].first)) throw IOException("Missing chunk file " + c.chunkFile);
+      continue;
+    }
     if (v[i].status != OZCS_OK) {
       if (rc == OZCS_ENODEV || rc == OZCS_EHIP || rc == OZCS_ENOMEM)
         throw GpuUnavailable(v[i].status, std::string("ozcs_verify_batch: ") + ozcs_last_error());
@@ -213,11 +238,15 @@ inline long long verifyChunks(const std::vector<std::pair<std::string, const Scr
 // the reference's order of events is replayed chunk by chunk, window by window, so the throttler sees exactly the
 // windows the reference would have read up to the failure and the first chunk (in order) that fails raises what
 // verifyChunkFile raises for it.  Returns the number of bytes read.
+// The loop's gate is the reference's (:241-256): chunks with stored type NONE are passed over unread and unthrottled; a
+// missing chunk file throws IOException("Missing chunk file <path>") at its turn unless blockStillExists(blockId)
+// says the block has left the table meanwhile (no callback: it is taken to be there).
 inline long long verifyBlock(const std::string& blockId, const std::vector<ScrubChunk>& chunks, ChunkLayOutVersion layout,
-                             const std::function<void(long long)>& throttler = {}) {
+                             const std::function<void(long long)>& throttler = {},
+                             const std::function<bool(const std::string&)>& blockStillExists = {}) {
   std::vector<std::pair<std::string, const ScrubChunk*>> flat;
   for (const ScrubChunk& c : chunks) flat.emplace_back(blockId, &c);
-  return detail::verifyChunks(flat, layout, throttler);
+  return detail::verifyChunks(flat, layout, throttler, blockStillExists);
 }
 
 // The data scan of one container, scanData (:226-257): every chunk of every block, in order.  Chunks are gathered
@@ -229,7 +258,8 @@ struct ScrubBlock {
   std::vector<ScrubChunk> chunks;
 };
 inline long long verifyContainer(const std::vector<ScrubBlock>& blocks, ChunkLayOutVersion layout,
-                                 const std::function<void(long long)>& throttler = {}, long long batchBytes = 1ll << 30) {
+                                 const std::function<void(long long)>& throttler = {}, long long batchBytes = 1ll << 30,
+                                 const std::function<bool(const std::string&)>& blockStillExists = {}) {
   long long total = 0, size = 0;
   std::vector<std::pair<std::string, const ScrubChunk*>> flat;
   for (const ScrubBlock& b : blocks) {
@@ -238,12 +268,12 @@ inline long long verifyContainer(const std::vector<ScrubBlock>& blocks, ChunkLay
       size += c.chunkLen;
     }
     if (size >= batchBytes) {
-      total += detail::verifyChunks(flat, layout, throttler);
+      total += detail::verifyChunks(flat, layout, throttler, blockStillExists);
       flat.clear();
       size = 0;
     }
   }
-  if (!flat.empty()) total += detail::verifyChunks(flat, layout, throttler);
+  if (!flat.empty()) total += detail::verifyChunks(flat, layout, throttler, blockStillExists);
   return total;
 }
 
@@ -334,14 +364,26 @@ class BlockOutputStream {
 
   // capacity = streamBufferMaxSize / streamBufferSize, the number of chunk buffers
   // (BlockOutputStreamEntryPool.java:91-96).
+  //
+  // safeByteStringConversion: the reference turns the chunk buffer into the request's ByteString before it computes
+  // the checksum (chunk.toByteString(bufferPool.byteStringConversion()), BlockOutputStream.java:648-649) -- a copy by
+  // default, a zero-copy wrap when unsafe conversion is configured.  true (default): the chunk's bytes are copied out
+  // of the pinned slot on submission and the pipe runs in in-order mode, so a slot goes back to the pool the moment
+  // the GPU is done with it (a CRC chunk does not hold its slot behind an older SHA-256 / MD5 chunk) while ChunkInfo
+  // records still leave in write order.  false: the slot itself is what is shipped and stays the chunk's until then.
   BlockOutputStream(long long localID, WriteChunkAsync writeChunkAsync, const OzoneClientConfig& config = OzoneClientConfig(),
-                    uint64_t streamBufferSize = 4u << 20, uint32_t capacity = 8, int device = 0)
+                    uint64_t streamBufferSize = 4u << 20, uint32_t capacity = 8, int device = 0,
+                    bool safeByteStringConversion = true)
       : localID_(localID), sink_(std::move(writeChunkAsync)), type_(config.getChecksumType()),
-        bpc_(config.getBytesPerChecksum()), bufferSize_(streamBufferSize) {
+        bpc_(config.getBytesPerChecksum()), bufferSize_(streamBufferSize), safe_(safeByteStringConversion) {
     const int t = (int)type_;
     if (t < OZCS_NONE || t > OZCS_MD5) throw OzoneChecksumException(type_);
-    const int rc = ozcs_pipe_create(device, capacity, streamBufferSize, &pipe_);
+    int rc = ozcs_pipe_create(device, capacity, streamBufferSize, &pipe_);
     if (rc != OZCS_OK) throw GpuUnavailable(rc, std::string("ozcs_pipe_create: ") + ozcs_last_error());
+    if (safe_ && (rc = ozcs_pipe_set_in_order(pipe_, 1)) != OZCS_OK) {
+      ozcs_pipe_destroy(pipe_);
+      throw GpuUnavailable(rc, std::string("ozcs_pipe_set_in_order: ") + ozcs_last_error());
+    }
   }
   ~BlockOutputStream() {
     try {
@@ -380,9 +422,8 @@ class BlockOutputStream {
       BlockOutputStream* s;
       ~Finally() {
         s->closed_ = true;
-        if (s->cur_) {  // acquired, never filled: give it back through an empty submission
-          (void)ozcs_pipe_submit_slot(s->pipe_, s->curTicket_, OZCS_NONE, 1, 0, nullptr, 0);
-          (void)ozcs_pipe_wait(s->pipe_, s->curTicket_, nullptr);
+        if (s->cur_) {  // acquired, never filled: give it back
+          (void)ozcs_pipe_release(s->pipe_, s->curTicket_);
           s->cur_ = nullptr;
         }
         ozcs_pipe_destroy(s->pipe_);
@@ -402,6 +443,7 @@ class BlockOutputStream {
     const char* data;
     std::string sums;
     uint64_t nsums;
+    std::string copy;  // safe conversion: the chunk's bytes, copied out of the slot on submission
   };
   void checkOpen() const {
     if (closed_) throw std::runtime_error("BlockOutputStream has been closed.");
@@ -409,10 +451,20 @@ class BlockOutputStream {
   void allocateNewBufferIfNeeded() {  // :281-286 over BufferPool.allocateBuffer
     if (cur_) return;
     int rc;
-    while ((rc = ozcs_pipe_acquire(pipe_, &cur_, &curTicket_)) == OZCS_EBUSY)
+    // in-order pipe: block for a slot (any completion gives one back); otherwise a slot is free only once its chunk
+    // has been shipped
+    while ((rc = safe_ ? ozcs_pipe_acquire_wait(pipe_, &cur_, &curTicket_) : ozcs_pipe_acquire(pipe_, &cur_, &curTicket_)) == OZCS_EBUSY) {
+      if (pending_.empty()) break;  // nothing of ours is in flight, yet no buffer is to be had: report it, do not spin
       shipOldest();  // every buffer is in flight: the reference waits for acknowledgements here (handleFullBuffer)
-    if (rc != OZCS_OK) throw GpuUnavailable(rc, std::string("ozcs_pipe_acquire: ") + ozcs_last_error());
+    }
+    if (rc != OZCS_OK) {
+      cur_ = nullptr;
+      throw GpuUnavailable(rc, std::string("ozcs_pipe_acquire: ") + ozcs_last_error());
+    }
     pos_ = 0;
+    if (safe_)
+      while (!pending_.empty() && shipOldest(false)) {
+      }
   }
   void writeChunk() {  // writeChunk + writeChunkToContainer, :495-507, :645-690
     const uint64_t n = pos_;
@@ -422,28 +474,46 @@ class BlockOutputStream {
     const int t = (int)type_;
     const uint64_t nsums = type_ == ChecksumType::NONE ? 0 : ozcs_num_checksums(n, (uint32_t)bpc_);
     pending_.push_back(Pending{curTicket_, ChunkInfo(std::to_string(localID_) + "_chunk_" + std::to_string(chunkIndex_), offset, (long long)n),
-                               static_cast<const char*>(cur_), std::string((size_t)(nsums * ozcs_digest_size(t)), '\0'), nsums});
+                               static_cast<const char*>(cur_), std::string((size_t)(nsums * ozcs_digest_size(t)), '\0'), nsums,
+                               safe_ ? std::string(static_cast<const char*>(cur_), (size_t)n) : std::string()});
     Pending& p = pending_.back();  // std::deque: the digest buffer does not move while the kernel writes it
+    // whatever the outcome, the buffer is no longer this stream's current one: a rejected submission has released
+    // the slot, an accepted one owns it
+    cur_ = nullptr;
+    pos_ = 0;
     const int rc = ozcs_pipe_submit_slot(pipe_, p.ticket, t, (uint32_t)bpc_, n, p.sums.empty() ? nullptr : &p.sums[0], p.sums.size());
     if (rc != OZCS_OK) {
       pending_.pop_back();
       throw GpuUnavailable(rc, std::string("ozcs_pipe_submit_slot: ") + ozcs_last_error());
     }
-    cur_ = nullptr;
   }
-  void shipOldest() {
+  // Ships the oldest submitted chunk once its digests are there; block = false (in-order pipe only) returns false
+  // instead of waiting for them.
+  bool shipOldest(bool block = true) {
+    if (pending_.empty()) throw std::runtime_error("no chunk is in flight");
     Pending& p = pending_.front();
     uint64_t got = 0;
-    const int rc = ozcs_pipe_wait(pipe_, p.ticket, &got);
-    if (rc != OZCS_OK) throw GpuUnavailable(rc, std::string("ozcs_pipe_wait: ") + ozcs_last_error());
+    if (safe_) {
+      int done = -1, status = OZCS_OK;
+      const int rc = ozcs_pipe_next_in_order(pipe_, block ? 1 : 0, &done, &status, &got);
+      if (rc == OZCS_EBUSY && !block) return false;
+      if (rc != OZCS_OK) throw GpuUnavailable(rc, std::string("ozcs_pipe_next_in_order: ") + ozcs_last_error());
+      if (status != OZCS_OK) throw GpuUnavailable(status, "a chunk's checksum failed on the GPU");
+      if (done != p.ticket) throw std::logic_error("the pipe delivered out of order");
+    } else {
+      const int rc = ozcs_pipe_wait(pipe_, p.ticket, &got);
+      if (rc != OZCS_OK) throw GpuUnavailable(rc, std::string("ozcs_pipe_wait: ") + ozcs_last_error());
+    }
     const size_t ds = ozcs_digest_size((int)type_);
     std::vector<ByteString> sums;
     for (uint64_t i = 0; i < got; i++) sums.emplace_back(p.sums.substr((size_t)i * ds, ds));
     p.info.setChecksumData(ChecksumData(type_, bpc_, std::move(sums)));
     chunks_.push_back(p.info);
-    // the slot is free again, but only this stream acquires from the pipe: its bytes stay until the next write
-    sink_(chunks_.back(), p.data, (size_t)p.info.getLen());
+    // unsafe conversion: the slot is free again, but only this stream acquires from the pipe, so its bytes stay
+    // until the next write
+    sink_(chunks_.back(), safe_ ? p.copy.data() : p.data, (size_t)p.info.getLen());
     pending_.pop_front();
+    return true;
   }
 
   long long localID_;
@@ -451,6 +521,7 @@ class BlockOutputStream {
   ChecksumType type_;
   int bpc_;
   uint64_t bufferSize_;
+  bool safe_;
   ozcs_pipe* pipe_ = nullptr;
   void* cur_ = nullptr;  // the buffer being filled and its ticket
   int curTicket_ = -1;

@@ -37,14 +37,21 @@ inline const char* name(ChecksumType t) {
 
 using ByteString = std::string;  // immutable byte sequence, as com.google.protobuf.ByteString
 
+// java.io.IOException, for the failures the callers report as such (a missing chunk file in the scrubber,
+// KeyValueContainerCheck.java:249-250) and as the base of OzoneChecksumException.
+class IOException : public std::runtime_error {
+ public:
+  explicit IOException(const std::string& message) : std::runtime_error(message) {}
+};
+
 // An IOException in the reference (callers fail over to the next replica on it).
-class OzoneChecksumException : public std::runtime_error {
+class OzoneChecksumException : public IOException {
  public:
   explicit OzoneChecksumException(int index)  // OzoneChecksumException.java:35-37
-      : std::runtime_error("Checksum mismatch at index " + std::to_string(index)), index_(index) {}
+      : IOException("Checksum mismatch at index " + std::to_string(index)), index_(index) {}
   explicit OzoneChecksumException(ChecksumType unrecognized)  // :43-47
-      : std::runtime_error(std::string("Unrecognized ChecksumType: ") + name(unrecognized)), index_(-1) {}
-  explicit OzoneChecksumException(const std::string& message) : std::runtime_error(message), index_(-1) {}  // :63-65
+      : IOException(std::string("Unrecognized ChecksumType: ") + name(unrecognized)), index_(-1) {}
+  explicit OzoneChecksumException(const std::string& message) : IOException(message), index_(-1) {}  // :63-65
   int index() const { return index_; }
 
  private:
@@ -207,10 +214,12 @@ class Checksum {
 
   // computeChecksum(List<ByteString>) / computeChecksum(ChunkBuffer over a list): one element per window; an
   // element longer than bytesPerChecksum contributes only its first bytesPerChecksum bytes
-  // (Checksum.java:148-153, 186-198).  By default every element is checksummed: the documented intent
-  // (Checksum.java:279-281) and what a Checksum patched to call this library yields.  referenceListQuirk = true
-  // reproduces the unpatched reference bit for bit: only the elements referenceListWindows() names.
-  ChecksumData computeChecksum(const std::vector<ByteString>& all, bool referenceListQuirk = false) const {
+  // (Checksum.java:148-153, 186-198).  By default (referenceListQuirk = true) the result is the reference's bit for
+  // bit: its list iterator stops early on lists of four or more elements, so only the elements
+  // referenceListWindows() names are checksummed -- the same default as ChunkBuffer::wrap(list), as both overloads
+  // share one iterator in the reference, and what a Checksum patched to call this library yields (the patch keeps
+  // the reference's iteration).  false checksums every element: the documented intent (Checksum.java:279-281).
+  ChecksumData computeChecksum(const std::vector<ByteString>& all, bool referenceListQuirk = true) const {
     std::vector<ByteString> subset;
     if (referenceListQuirk) {
       std::vector<size_t> lengths;
@@ -267,7 +276,7 @@ class Checksum {
 
   // verifyChecksum(List<ByteString>, ChecksumData, int, boolean): Checksum.java:265-290.
   static bool verifyChecksum(const std::vector<ByteString>& byteStrings, const ChecksumData& checksumData,
-                             int startIndex, bool isSingleByteString, bool referenceListQuirk = false) {
+                             int startIndex, bool isSingleByteString, bool referenceListQuirk = true) {
     if (checksumData.getChecksumType() == ChecksumType::NONE) return true;  // :269-272
     if (isSingleByteString)
       return verifyChecksum(byteStrings.at(0).data(), byteStrings.at(0).size(), checksumData, startIndex);  // :274-277

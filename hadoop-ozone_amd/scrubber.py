@@ -105,13 +105,30 @@ def verifyChunkProto(block_id, chunk_proto, chunk_file, layout, throttler=None, 
                           chunk_file, layout, throttler, canceler)
 
 
-def _verify_chunks(flat, layout, throttler, canceler):
+_MISSING, _SKIPPED = "missing", "skipped"
+
+
+def _verify_chunks(flat, layout, throttler, canceler, block_still_exists=None):
     """flat: list of (block_id, (chunk_name, chunk_offset, chunk_len, checksum_data, chunk_file)).  All chunks are
-    read and hashed by ONE ozcs_verify_batch call; then the reference's order of events is replayed chunk by chunk."""
+    read and hashed by ONE ozcs_verify_batch call; then the reference's order of events is replayed chunk by chunk.
+
+    The per-chunk gate of scanData (KeyValueContainerCheck.java:241-256) is applied first: a chunk whose file does not
+    exist is not read -- at its turn in the replay the block is looked up again (block_still_exists(block_id); the
+    reference asks the block table, :243-247) and "Missing chunk file <path>" is raised if it is still there, else
+    the chunk is passed over (the block was deleted meanwhile); a chunk whose stored checksum type is NONE is passed
+    over as well: not read, not throttled, not judged (:252-253)."""
     import ctypes
+    import os
     import numpy as np
     reads = []
+    empty = np.zeros(0, dtype=np.uint8)
     for bid, (name, off, ln, cd, path) in flat:
+        if not os.path.exists(path):
+            reads.append((empty, b"", _MISSING))
+            continue
+        if cd.getChecksumType() == ChecksumType.NONE:
+            reads.append((empty, b"", _SKIPPED))
+            continue
         data = _read_chunk(off, ln, cd, path, layout)
         bpc = cd.getBytesPerChecksum()
         nwin = (len(data) + bpc - 1) // bpc if bpc else 0
@@ -120,6 +137,10 @@ def _verify_chunks(flat, layout, throttler, canceler):
     arr = (native.OzcsVChunk * max(1, n))()
     for i, ((bid, (name, off, ln, cd, path)), (data, stored, nwin)) in enumerate(zip(flat, reads)):
         t = cd.getChecksumType()
+        if nwin in (_MISSING, _SKIPPED):
+            arr[i].type = int(ChecksumType.NONE)                   # nothing for the GPU to do
+            arr[i].bpc = 1
+            continue
         arr[i].type = int(t) if nwin else int(ChecksumType.NONE)   # nothing read: only the length check applies
         arr[i].bpc = cd.getBytesPerChecksum()
         arr[i].data = data.ctypes.data if data.size else None
@@ -130,6 +151,13 @@ def _verify_chunks(flat, layout, throttler, canceler):
     rc = native.lib().ozcs_verify_batch(arr, n) if n else native.OK
     total = 0
     for i, ((bid, (name, off, ln, cd, path)), (data, stored, nwin)) in enumerate(zip(flat, reads)):
+        if nwin == _SKIPPED:
+            continue                                               # :252-253
+        if nwin == _MISSING:
+            # "concurrent mutation in Block DB? lookup the block again" (:242-251)
+            if block_still_exists is None or block_still_exists(bid):
+                raise IOError("Missing chunk file " + os.path.abspath(path))
+            continue
         if arr[i].status != native.OK:
             if rc in (native.ENODEV, native.EHIP, native.ENOMEM):
                 native.check(arr[i].status)
@@ -138,24 +166,29 @@ def _verify_chunks(flat, layout, throttler, canceler):
     return total
 
 
-def verifyBlock(block_id, chunks, layout, throttler=None, canceler=None):
+def verifyBlock(block_id, chunks, layout, throttler=None, canceler=None, block_still_exists=None):
     """The `for chunk in block.getChunks()` loop of KeyValueContainerCheck.scanData (:235-257) with ONE
-    ozcs_verify_batch call for all chunks instead of one checksum call per window.
+    ozcs_verify_batch call for all chunks instead of one checksum call per window, the loop's gate included
+    (:241-256): a chunk with stored type NONE is passed over unread and unthrottled; a chunk whose file is missing
+    raises IOError("Missing chunk file <absolute path>") at its turn if block_still_exists(block_id) says the block
+    is still in the table (default: it is), and is passed over otherwise.
 
     chunks: list of (chunk_name, chunk_offset, chunk_len, checksum_data, chunk_file).  All chunks are read and
     hashed in bulk first; then the reference's order of events is replayed chunk by chunk, window by window
     (throttle, judge, stop at the first failure): the throttler sees exactly the windows the reference would
     have read up to the failure, and the first chunk (in order) that fails raises what verifyChecksum raises
     for it.  Returns the number of bytes read."""
-    return _verify_chunks([(block_id, c) for c in chunks], layout, throttler, canceler)
+    return _verify_chunks([(block_id, c) for c in chunks], layout, throttler, canceler, block_still_exists)
 
 
-def verifyContainer(blocks, layout, throttler=None, canceler=None, batch_bytes=1 << 30):
+def verifyContainer(blocks, layout, throttler=None, canceler=None, batch_bytes=1 << 30, block_still_exists=None):
     """The data scan of one container, KeyValueContainerCheck.scanData (:226-257): every chunk of every block, in
     order.  Chunks are gathered across block boundaries into batches of about `batch_bytes` of stored length, each
     batch one ozcs_verify_batch call; the reference's order of events is then replayed chunk by chunk, so the first
     failing chunk of the first failing block raises what verifyChecksum raises for it and nothing behind it is
-    throttled.  (A chunk behind a failure may already have been read: reads run ahead by at most one batch.)
+    throttled.  (A chunk behind a failure may already have been read: reads run ahead by at most one batch.)  The
+    per-chunk gate is the reference's (:241-256, see verifyBlock): NONE chunks are passed over, a missing chunk file
+    of a block that block_still_exists(block_id) confirms raises "Missing chunk file ...".
 
     blocks: list of (block_id, chunks) with chunks as in verifyBlock.  Returns the number of bytes read."""
     total = 0
@@ -165,7 +198,7 @@ def verifyContainer(blocks, layout, throttler=None, canceler=None, batch_bytes=1
         nonlocal total, batch, size
         # one call for the whole batch; replay needs every chunk's block id
         flat = [(bid, c) for bid, chunks in batch for c in chunks]
-        total += _verify_chunks(flat, layout, throttler, canceler)
+        total += _verify_chunks(flat, layout, throttler, canceler, block_still_exists)
         batch, size = [], 0
 
     for bid, chunks in blocks:

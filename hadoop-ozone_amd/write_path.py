@@ -11,6 +11,14 @@ buffers are the pinned slots of an ozcs pipe (in place of BufferPool's heap buff
 buffer is submitted and the writer goes on filling the next one while the first is copied and hashed; chunks are
 handed to `writeChunkAsync` strictly in order, each as soon as its digests have arrived.  What comes out -- the
 ChunkInfo records and the bytes -- is what the reference would ship.
+
+The reference turns the chunk buffer into the request's ByteString before it computes the checksum
+(chunk.toByteString(bufferPool.byteStringConversion()), :648-649): a copy by default, a zero-copy wrap when
+ozone.client.stream.buffer... unsafe conversion is configured.  Both are here:
+  * "safe" (default): the chunk's bytes are copied out of the pinned slot when it is submitted, and the pipe runs in
+    in-order mode -- a slot goes back to the pool the moment the GPU is done with it, so a CRC chunk does not hold its
+    slot behind an older SHA-256 / MD5 chunk, while ChunkInfo records still leave in the order of the writes;
+  * "unsafe": the slot itself is what is shipped, so it stays the chunk's until its turn to be shipped has come.
 """
 import ctypes
 
@@ -30,10 +38,14 @@ def writeSmallFileChunkInfo(localID, data):
 
 
 class BlockOutputStream:
-    def __init__(self, localID, writeChunkAsync, config=None, streamBufferSize=4 << 20, capacity=8, device=0):
+    def __init__(self, localID, writeChunkAsync, config=None, streamBufferSize=4 << 20, capacity=8, device=0,
+                 byteStringConversion="safe"):
         """writeChunkAsync(chunkInfo: ChunkInfo, data: bytes) receives every chunk, in order (ContainerProtocolCalls
         .writeChunkAsync in the reference).  capacity = streamBufferMaxSize / streamBufferSize, the number of chunk
-        buffers (BlockOutputStreamEntryPool.java:91-96)."""
+        buffers (BlockOutputStreamEntryPool.java:91-96).  byteStringConversion: "safe" or "unsafe", see the module text."""
+        if byteStringConversion not in ("safe", "unsafe"):
+            raise ValueError(byteStringConversion)
+        self.safe = byteStringConversion == "safe"
         self.config = config or OzoneClientConfig()
         self.type = self.config.getChecksumType()
         self.bpc = self.config.getBytesPerChecksum()
@@ -53,6 +65,8 @@ class BlockOutputStream:
             raise OzoneChecksumException(("type", self.type))
         self._pipe = ctypes.c_void_p()
         native.check(self._L.ozcs_pipe_create(device, capacity, streamBufferSize, ctypes.byref(self._pipe)))
+        if self.safe:
+            native.check(self._L.ozcs_pipe_set_in_order(self._pipe, 1))
 
     # ---- BlockOutputStream.write(byte[], off, len), :241-266
     def write(self, b, off=0, length=None):
@@ -89,9 +103,8 @@ class BlockOutputStream:
             self.flush()
         finally:
             self._closed = True
-            if self._cur is not None:   # acquired, never filled: give it back through an empty submission
-                self._L.ozcs_pipe_submit_slot(self._pipe, self._cur[1], int(ChecksumType.NONE), 1, 0, None, 0)
-                self._L.ozcs_pipe_wait(self._pipe, self._cur[1], None)
+            if self._cur is not None:   # acquired, never filled: give it back
+                self._L.ozcs_pipe_release(self._pipe, self._cur[1])
                 self._cur = None
             self._L.ozcs_pipe_destroy(self._pipe)
             self._pipe = None
@@ -109,12 +122,19 @@ class BlockOutputStream:
             return
         buf, ticket = ctypes.c_void_p(), ctypes.c_int()
         while True:
-            rc = self._L.ozcs_pipe_acquire(self._pipe, ctypes.byref(buf), ctypes.byref(ticket))
+            # in-order pipe: block for a slot (any completion gives one back); otherwise a slot is free only once its
+            # chunk has been shipped
+            acquire = self._L.ozcs_pipe_acquire_wait if self.safe else self._L.ozcs_pipe_acquire
+            rc = acquire(self._pipe, ctypes.byref(buf), ctypes.byref(ticket))
             if rc != native.EBUSY:
                 break
+            if not self._pending:   # nothing of ours is in flight, yet no buffer is to be had: report it, do not spin
+                native.check(rc)
             self._ship_oldest()   # every buffer is in flight: the reference waits for acknowledgements here (handleFullBuffer)
         native.check(rc)
         self._cur, self._pos = (buf.value, ticket.value), 0
+        if self.safe:
+            self._ship_ready()
 
     def _write_chunk(self):  # writeChunk + writeChunkToContainer, :495-507, :645-690
         addr, ticket = self._cur
@@ -126,17 +146,38 @@ class BlockOutputStream:
         ds = native.DIGEST_SIZE[int(self.type)]
         nsums = 0 if self.type == ChecksumType.NONE else (n + self.bpc - 1) // self.bpc
         out = ctypes.create_string_buffer(max(1, nsums * ds))
+        data = ctypes.string_at(addr, n) if self.safe else None   # chunk.toByteString's copy (:648-649)
+        # whatever the outcome, the buffer is no longer this stream's current one: a rejected submission has released
+        # the slot, an accepted one owns it
+        self._cur, self._pos = None, 0
         native.check(self._L.ozcs_pipe_submit_slot(self._pipe, ticket, int(self.type), self.bpc, n, out, nsums * ds))
-        self._pending.append((ticket, info, addr, out, nsums, ds))
-        self._cur = None
+        self._pending.append((ticket, info, addr, out, nsums, ds, data))
 
-    def _ship_oldest(self):
-        ticket, info, addr, out, nsums, ds = self._pending.pop(0)
+    def _ship_ready(self):
+        """In-order pipe: ships every chunk at the head of the queue whose digests have arrived, without waiting."""
+        while self._pending and self._ship_oldest(block=0):
+            pass
+
+    def _ship_oldest(self, block=1):
+        if not self._pending:
+            raise IOError("no chunk is in flight")
+        ticket, info, addr, out, nsums, ds, data = self._pending[0]
         got = ctypes.c_uint64()
-        native.check(self._L.ozcs_pipe_wait(self._pipe, ticket, ctypes.byref(got)))
+        if self.safe:
+            done, status = ctypes.c_int(-1), ctypes.c_int(0)
+            rc = self._L.ozcs_pipe_next_in_order(self._pipe, block, ctypes.byref(done), ctypes.byref(status), ctypes.byref(got))
+            if rc == native.EBUSY and not block:
+                return False
+            native.check(rc)
+            assert done.value == ticket, (done.value, ticket)
+            native.check(status.value)
+        else:
+            native.check(self._L.ozcs_pipe_wait(self._pipe, ticket, ctypes.byref(got)))
+            data = ctypes.string_at(addr, info.getLen())   # the slot is free now, but only this stream acquires from the pipe
+        self._pending.pop(0)
         assert got.value == nsums
-        data = ctypes.string_at(addr, info.getLen())   # the slot is free now, but only this stream acquires from the pipe
         raw = out.raw[:nsums * ds]
         info.setChecksumData(ChecksumData(self.type, self.bpc, [raw[i:i + ds] for i in range(0, len(raw), ds)] if ds else []))
         self.chunks.append(info)
         self.sink(info, data)
+        return True

@@ -292,7 +292,8 @@ typedef struct ozcs_stats {
                                 falling back to its own CPU path (the library itself has none) */
   /* Phase times of the synchronous host-pointer calls (ozcs_compute, ozcs_verify and each staged group of the
    * batched calls), measured with HIP events on the call's own stream for one call in OZCS_STATS_SAMPLE_EVERY
-   * (the first call of a thread pool slot included), so that the events cost nothing on the others: */
+   * (counted over all threads, the first call of the process included), so that the events cost nothing on the
+   * others: */
   uint64_t timed_calls;      /* calls (or groups) that were timed */
   uint64_t timed_bytes;      /* their input bytes */
   uint64_t h2d_us;           /* host-to-device copies, microseconds, summed over the timed calls */

@@ -64,7 +64,7 @@ int main() {
   const ChecksumData cd = c20.computeChecksum(whole.data(), whole.size());
   std::vector<ByteString> windows;
   for (int i = 0; i < 100; i += 20) windows.push_back(whole.substr(i, 20));
-  EXPECT(c20.computeChecksum(windows) == cd);
+  EXPECT(c20.computeChecksum(windows, false) == cd);   // every element; the default follows the reference's iterator
   EXPECT(Checksum::verifyChecksum(std::vector<ByteString>(windows.begin() + 1, windows.begin() + 3), cd, 1, false));
   EXPECT(Checksum::verifyChecksum(std::vector<ByteString>{whole.substr(20, 40)}, cd, 1, true));
   try {
@@ -177,16 +177,24 @@ int main() {
     for (int o = 0; o < 100; o += 20) parts.push_back(bytes.substr(o, 20));
     const std::vector<ByteString> full = oracle_sums(ChecksumType::CRC32, 20, bytes);
     const Checksum ck(ChecksumType::CRC32, 20);
-    EXPECT(ck.computeChecksum(parts).getChecksums() == full);
+    EXPECT(ck.computeChecksum(parts, false).getChecksums() == full);
+    // the default is the reference's result, and equal to the ChunkBuffer route (Checksum.java:148-153 share one iterator)
+    EXPECT(ck.computeChecksum(parts).getChecksums() == std::vector<ByteString>(full.begin(), full.begin() + 4));
     EXPECT(ck.computeChecksum(parts, true).getChecksums() == std::vector<ByteString>(full.begin(), full.begin() + 4));
+    {
+      std::vector<ByteBufferPtr> bufs;
+      for (const ByteString& p : parts) bufs.push_back(ByteBuffer::wrapReadOnly(p.data(), p.size()));
+      EXPECT(ck.computeChecksum(*ChunkBuffer::wrap(bufs)) == ck.computeChecksum(parts));
+    }
     std::vector<ByteString> bad = parts;
     bad[4][0] ^= 1;
     const ChecksumData stored(ChecksumType::CRC32, 20, full);
     try {
-      Checksum::verifyChecksum(bad, stored, 0, false);
+      Checksum::verifyChecksum(bad, stored, 0, false, false);
       EXPECT(!"corrupt fifth window accepted");
     } catch (const OzoneChecksumException& e) { EXPECT(e.index() == 4); }
-    EXPECT(Checksum::verifyChecksum(bad, stored, 0, false, true));   // the unpatched reference never looks at it
+    EXPECT(Checksum::verifyChecksum(bad, stored, 0, false));         // the reference never looks at it: the default
+    EXPECT(Checksum::verifyChecksum(bad, stored, 0, false, true));
   }
 
   // ---- scrubber: TestKeyValueContainerCheck shape (SHA-256, ragged last window), both layouts ----
@@ -287,6 +295,28 @@ int main() {
     }
     put(file);
     EXPECT(verifyContainer(blocks, ChunkLayOutVersion::FILE_PER_BLOCK) == 3 * chunkLen);
+    // scanData's gate (KeyValueContainerCheck.java:241-256): a chunk of stored type NONE between two CRC32C chunks is
+    // passed over (its bytes never reach the throttler); a missing file is an IOException unless the block has gone
+    std::vector<ScrubChunk> gated = chunks;
+    gated[1].checksumData = ChecksumData(ChecksumType::NONE, bpc, {"stale"});
+    throttled = 0;
+    EXPECT(verifyBlock("blk#9", gated, ChunkLayOutVersion::FILE_PER_BLOCK, [&](long long n) { throttled += n; }) == 2 * chunkLen);
+    EXPECT(throttled == 2 * chunkLen);
+    gated[2].chunkFile = path + ".gone";
+    seen.clear();
+    try {
+      verifyBlock("blk#9", gated, ChunkLayOutVersion::FILE_PER_BLOCK, [&](long long n) { seen.push_back(n); });
+      EXPECT(!"missing chunk file accepted");
+    } catch (const OzoneChecksumException&) {
+      EXPECT(!"a missing file is a plain IOException");
+    } catch (const IOException& e) {
+      EXPECT(std::string(e.what()) == "Missing chunk file " + path + ".gone");
+      EXPECT(seen.size() == 10);   // chunk 0 was scanned first
+    }
+    std::vector<std::string> asked;
+    EXPECT(verifyContainer({ScrubBlock{"blk#9", gated}}, ChunkLayOutVersion::FILE_PER_BLOCK, {}, 1ll << 30,
+                           [&](const std::string& id) { asked.push_back(id); return false; }) == chunkLen);
+    EXPECT(asked == std::vector<std::string>{"blk#9"});
     std::remove(path.c_str());
   }
 
@@ -371,8 +401,11 @@ int main() {
   // BlockOutputStream over the pinned pipe, in the shape of TestBlockOutputStreamCorrectness.java: seeded bytes
   // written in odd pieces; what reaches writeChunkAsync is the same bytes cut into chunks of the buffer size, each
   // with the ChunkInfo the reference builds (BlockOutputStream.java:645-656), checksums included
-  for (const char* typeName : {"CRC32", "SHA256", "NONE"}) {
+  for (const char* typeSpec : {"CRC32", "SHA256", "NONE", "CRC32/unsafe", "SHA256/unsafe"}) {
     typedef std::map<std::string, std::string> Conf;
+    const std::string spec(typeSpec);
+    const bool safe = spec.find("/unsafe") == std::string::npos;   // chunk.toByteString: a copy (default) or a wrap
+    const std::string typeName = spec.substr(0, spec.find('/'));
     OzoneClientConfig cfg(Conf{{"ozone.client.checksum.type", typeName}, {"ozone.client.bytes.per.checksum", "256KB"}});
     const size_t total = 6 * (1u << 20) + 12345;
     std::string payload(total, '\0');
@@ -380,7 +413,7 @@ int main() {
     std::vector<std::pair<ChunkInfo, std::string>> shipped;
     {
       BlockOutputStream out(777, [&](const ChunkInfo& info, const char* d, size_t n) { shipped.emplace_back(info, std::string(d, n)); },
-                            cfg, 1u << 20, 3);
+                            cfg, 1u << 20, 3, 0, safe);
       const size_t pieces[5] = {1, 4099, 600001, 77, 262144};
       size_t pos = 0;
       for (int k = 0; pos < total; k++) {

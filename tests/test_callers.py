@@ -167,7 +167,8 @@ def test_verify_batch_matches_verify():
 
 @pytest.mark.gpu
 def test_list_inputs_default_and_reference_quirk():
-    # computeChecksum(List<ByteString>) / V1 verify: all elements by default, the reference's subset on request
+    # computeChecksum(List<ByteString>) / V1 verify: the reference's subset by default (one default for the list overload
+    # and ChunkBuffer.wrap(list), as both share one iterator in the reference), all elements on request
     from hadoop_ozone_amd import Checksum
     from hadoop_ozone_amd.checksum import reference_list_windows
     bpc = 20
@@ -175,15 +176,21 @@ def test_list_inputs_default_and_reference_quirk():
     parts = [data[o:o + bpc] for o in range(0, 100, bpc)]
     full = [oracle.compute(oracle.CRC32, bpc, p) for p in parts]
     ck = Checksum(ChecksumType.CRC32, bpc)
-    assert ck.computeChecksum(parts).getChecksums() == full
+    assert ck.computeChecksum(parts, reference_list_quirk=False).getChecksums() == full
     quirk = ck.computeChecksum(parts, reference_list_quirk=True).getChecksums()
     assert quirk == full[:4] and reference_list_windows([20] * 5) == [0, 1, 2, 3]
+    from hadoop_ozone_amd.chunk_buffer import ByteBuffer, ChunkBuffer
+    for k in (1, 3, 4, 5):
+        sub = parts[:k]
+        assert ck.computeChecksum(sub) == ck.computeChecksum(ChunkBuffer.wrap([ByteBuffer.wrap(p) for p in sub]))
+    assert ck.computeChecksum(parts).getChecksums() == quirk
     stored = ChecksumData(ChecksumType.CRC32, bpc, full)
     bad = list(parts)
     bad[4] = bytes([bad[4][0] ^ 1]) + bad[4][1:]          # corruption in the fifth window
     with pytest.raises(OzoneChecksumException, match="Checksum mismatch at index 4"):
-        Checksum.verifyChecksum(bad, stored, 0, False)
-    # the unpatched reference never looks at window 4 of this list and accepts it
+        Checksum.verifyChecksum(bad, stored, 0, False, reference_list_quirk=False)
+    # the reference never looks at window 4 of this list and accepts it: the default
+    assert Checksum.verifyChecksum(bad, stored, 0, False) is True
     assert Checksum.verifyChecksum(bad, stored, 0, False, reference_list_quirk=True) is True
     bad2 = list(parts)
     bad2[1] = bytes([bad2[1][0] ^ 1]) + bad2[1][1:]
@@ -247,7 +254,8 @@ def test_scrubber_takes_the_chunk_as_its_wire_record(tmp_path):
                                   {"ozone.client.checksum.type": "MD5", "ozone.client.bytes.per.checksum": "256KB"},
                                   {"ozone.client.checksum.type": "NONE"}],
                          ids=["defaults", "crc32c-16k", "md5-256k", "none"])
-def test_write_path_like_TestBlockOutputStreamCorrectness(conf):
+@pytest.mark.parametrize("conversion", ["safe", "unsafe"])
+def test_write_path_like_TestBlockOutputStreamCorrectness(conf, conversion):
     # TestBlockOutputStreamCorrectness.java: seeded random bytes written in odd pieces through BlockOutputStream with
     # 4 MB buffers; what reaches writeChunkAsync must be the same bytes, cut into chunks of the buffer size, each with
     # the ChunkInfo the reference builds (BlockOutputStream.java:645-656) -- here checksums included
@@ -257,7 +265,8 @@ def test_write_path_like_TestBlockOutputStreamCorrectness(conf):
     total = 6 * (1 << 20) + 12345
     payload = oracle.splitmix64(2024, total).tobytes()
     shipped = []
-    out = BlockOutputStream(777, lambda info, data: shipped.append((info, data)), cfg, streamBufferSize=1 << 20, capacity=3)
+    out = BlockOutputStream(777, lambda info, data: shipped.append((info, data)), cfg, streamBufferSize=1 << 20, capacity=3,
+                            byteStringConversion=conversion)
     pos, k = 0, 0
     while pos < total:   # writes of 1 B .. ~600 KiB that never line up with the buffers
         n = min(total - pos, (1, 4099, 600001, 77, 262144)[k % 5])
@@ -378,3 +387,47 @@ def test_scrubber_whole_container_in_batches(tmp_path):
     with pytest.raises(OzoneChecksumException, match=r"chunkName='b1c2, offset=98304, len=49152\} checksum item 2 expected .* for block blk1"):
         scrubber.verifyContainer(blocks, scrubber.FILE_PER_BLOCK, throttler=lambda n, c: seen.append(n), batch_bytes=15 * chunk_len)
     assert len(seen) == (6 + 2) * 3 + 3   # block 0 whole, block 1 chunks 0-1 whole, chunk 2 up to its failing window
+
+
+@pytest.mark.gpu
+def test_scrubber_gate_none_chunks_skipped_and_missing_files_reported(tmp_path):
+    # scanData's per-chunk gate (KeyValueContainerCheck.java:241-256): a chunk whose stored type is NONE is passed over --
+    # not read, not throttled, not judged; a missing chunk file raises "Missing chunk file <path>" when the block is still
+    # in the table, and is passed over when the block has gone meanwhile
+    chunk_len, bpc = 5 * 4096, 4096
+    datas = [oracle.splitmix64(3000 + i, chunk_len).tobytes() for i in range(3)]
+    crc = lambda d: ChecksumData(ChecksumType.CRC32, bpc, [oracle.compute(oracle.CRC32, bpc, d[o:o + bpc]) for o in range(0, chunk_len, bpc)])  # noqa: E731
+    files = [tmp_path / ("c%d.chunk" % i) for i in range(3)]
+    for f, d in zip(files, datas):
+        f.write_bytes(d)
+    chunks = [("c0", 0, chunk_len, crc(datas[0]), str(files[0])),
+              ("c1", 0, chunk_len, ChecksumData(ChecksumType.NONE, bpc), str(files[1])),     # NONE between two CRC32 chunks
+              ("c2", 0, chunk_len, crc(datas[2]), str(files[2]))]
+    seen = []
+    total = scrubber.verifyBlock("blk", chunks, scrubber.FILE_PER_CHUNK, throttler=lambda n, c: seen.append(n))
+    assert total == 2 * chunk_len and seen == [bpc] * 10             # the NONE chunk's bytes never reach the throttler
+    files[1].write_bytes(b"garbage")                                  # ... and its content is never looked at
+    assert scrubber.verifyContainer([("blk", chunks)], scrubber.FILE_PER_CHUNK) == 2 * chunk_len
+    # a NONE chunk that even carries stale stored checksums is skipped as well (the gate looks at the type only)
+    stale = list(chunks)
+    stale[1] = ("c1", 0, chunk_len, ChecksumData(ChecksumType.NONE, bpc, [b"abcd"] * 5), str(files[1]))
+    assert scrubber.verifyBlock("blk", stale, scrubber.FILE_PER_CHUNK) == 2 * chunk_len
+    # missing file of a chunk of a block that is still in the table: the reference's IOException, at that chunk's turn
+    files[2].unlink()
+    seen.clear()
+    with pytest.raises(IOError, match="^Missing chunk file " + str(files[2]) + "$") as ei:
+        scrubber.verifyBlock("blk", chunks, scrubber.FILE_PER_CHUNK, throttler=lambda n, c: seen.append(n))
+    assert not isinstance(ei.value, OzoneChecksumException) and seen == [bpc] * 5      # chunk 0 was scanned first
+    asked = []
+    with pytest.raises(IOError, match="Missing chunk file"):
+        scrubber.verifyContainer([("blk", chunks)], scrubber.FILE_PER_CHUNK,
+                                 block_still_exists=lambda bid: asked.append(bid) or True)
+    assert asked == ["blk"]
+    # the block was deleted between the iterator and the lookup: no error, the chunk is passed over
+    assert scrubber.verifyContainer([("blk", chunks)], scrubber.FILE_PER_CHUNK, block_still_exists=lambda bid: False) == chunk_len
+    # an earlier checksum failure wins over a later missing file
+    raw = bytearray(datas[0])
+    raw[4096 + 1] ^= 2
+    files[0].write_bytes(bytes(raw))
+    with pytest.raises(OzoneChecksumException, match="checksum item 1 expected"):
+        scrubber.verifyBlock("blk", chunks, scrubber.FILE_PER_CHUNK)

@@ -160,7 +160,7 @@ def test_stats_phase_times_of_host_pointer_calls(gpu):
         native.compute(native.CRC32, MIB, d)
     after = native.stats()
     timed = after["timed_calls"] - before["timed_calls"]
-    assert 2 <= timed <= 4, timed                                       # 40 calls on one context: calls 0/16/32 (+ phase)
+    assert 2 <= timed <= 3, timed                                       # 40 calls, one in 16 timed
     assert after["timed_bytes"] - before["timed_bytes"] == timed * 8 * MIB
     h2d, ker, d2h = (after[k] - before[k] for k in ("h2d_us", "kernel_us", "d2h_us"))
     # 8 MiB over PCIe takes 150 us at the very least and under 10 ms; the kernel some microseconds

@@ -1,5 +1,5 @@
 // Measures what a pure streaming read reaches on this GPU, in the access patterns the CRC kernel could use.
-// Build: hipcc --offload-arch=gfx950 -O3 -o tools/hbm_read_bench tools/hbm_read_bench.hip
+// Build: make -C tools   (hipcc --offload-arch=gfx950 -O3 -o tools/hbm_read_bench tools/hbm_read_bench.hip)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -226,6 +226,13 @@ int main(int argc, char** argv) {
   const uint64_t n16 = bytes / 16, win = 1 << 20, nwin = bytes / win;
   const u32x4* p = (const u32x4*)d;
   printf("buffer %llu GiB\n", (unsigned long long)(bytes >> 30));
+  if (argc > 2 && !strcmp(argv[2], "crc")) {   // only the 1 MiB-window CRC kernel's own pattern, for bench.py's ceiling line
+    timeit("crc pattern G=1 (prefetch 1, nt)", bytes, [&] { read_crc_pattern<1><<<256, 1024>>>(d, nwin, win, out); });
+    timeit("crc pattern G=2 (prefetch 1, nt)", bytes, [&] { read_crc_pattern<2><<<256, 1024>>>(d, nwin, win, out); });
+    timeit("crc pattern G=4 (prefetch 1, nt)", bytes, [&] { read_crc_pattern<4><<<256, 1024>>>(d, nwin, win, out); });
+    timeit("crc pattern G=8 (prefetch 1, nt)", bytes, [&] { read_crc_pattern<8><<<256, 1024>>>(d, nwin, win, out); });
+    return 0;
+  }
   if (argc > 2 && !strcmp(argv[2], "flat")) {   // bare reads in the small-window kernels' pattern, window size x lanes per window
     std::vector<uint32_t> sizes = {512u, 2048u, 4096u, 8192u, 16384u, 32768u, 65536u, 131072u};
     if (argc > 3 && !strcmp(argv[3], "large")) sizes = {262144u, 524288u, 1048576u};
