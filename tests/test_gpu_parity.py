@@ -856,3 +856,60 @@ def test_device_entry_points_under_graph_capture(gpu):
         assert bytes(sums.cpu().numpy()) == oracle_chunks(oracle.CRC32C, bpc, host, chunk, n_chunks, chunk)
         assert bytes(big.cpu().numpy()) == oracle_chunks(oracle.CRC32, MIB, host, chunk, n_chunks, chunk)
         assert fm.cpu().tolist() == [-1] * n_chunks
+
+
+@pytest.mark.parametrize("t,bpc,gib", [(oracle.CRC32, 16384, 1), (oracle.CRC32C, 32768, 2)])
+def test_default_kernel_selection_four_phase_flat_crc(gpu, t, bpc, gib):
+    # No launcher override: a gapless, 16-byte aligned batch of at least 16 windows per wavefront of the chip (65,536
+    # windows on 256 CUs) takes the kernel the launcher itself picks there -- 8 lanes per window with four phases at
+    # 16 KiB, 32 lanes with four phases at 32 KiB.  Every digest is compared with the oracle, compute and verify.
+    import os
+    torch, native, L = gpu
+    assert not any(k.startswith("OZCS_CRC_") for k in os.environ), "launcher overrides are set"
+    n = gib << 30
+    assert n // bpc >= 65536
+    g = torch.Generator(device="cuda")
+    g.manual_seed(777 + bpc)
+    d = torch.empty(n, dtype=torch.uint8, device="cuda")
+    d.view(torch.int64).random_(generator=g)
+    host = d.cpu().numpy()
+    chunk = 4 * MIB
+    got = dev_compute(gpu, t, bpc, d, chunk, n // chunk, chunk)
+    want = oracle.compute(t, bpc, host)            # chunks back to back, bpc divides the chunk: one run of windows
+    assert got == want
+    # verify with the launcher's own choice as well: clean, then one flipped byte in the last window of a middle chunk
+    ds, wpc, nch = 4, chunk // bpc, n // chunk
+    stored = torch.from_numpy(np.frombuffer(want, dtype=np.uint8).copy()).cuda()
+    fm = torch.zeros(nch, dtype=torch.int64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    native.check(L.ozcs_verify_device(0, t, bpc, d.data_ptr(), chunk, nch, chunk, stored.data_ptr(), wpc * ds, wpc, 0,
+                                      fm.data_ptr(), stream))
+    torch.cuda.synchronize()
+    assert int(fm.max()) == -1 and int(fm.min()) == -1
+    c = nch // 2
+    d[c * chunk + chunk - 3] ^= 0x20
+    native.check(L.ozcs_verify_device(0, t, bpc, d.data_ptr(), chunk, nch, chunk, stored.data_ptr(), wpc * ds, wpc, 0,
+                                      fm.data_ptr(), stream))
+    torch.cuda.synchronize()
+    v = fm.cpu().numpy()
+    assert v[c] == wpc - 1 and (np.delete(v, c) == -1).all()
+
+
+@pytest.mark.parametrize("t", [oracle.SHA256, oracle.MD5])
+def test_default_kernel_selection_whole_line_digest_loaders(gpu, t):
+    # No override: from eight wavefronts per CU on (131,072 windows on 256 CUs) the launcher takes the loaders that
+    # fetch whole 128-byte lines per step.  Every digest is compared with the oracle.
+    import os
+    torch, native, L = gpu
+    assert "OZCS_SHA_LINES" not in os.environ and "OZCS_MD5_LINES" not in os.environ and "OZCS_SHA_SPLIT" not in os.environ
+    bpc, nwin = 1024, 131072 + 64
+    chunk = 64 * bpc + 520                          # a ragged last window of 520 bytes per chunk: 65 windows a chunk
+    nch = (nwin + 64) // 65
+    g = torch.Generator(device="cuda")
+    g.manual_seed(4242 + t)
+    d = torch.empty(nch * chunk, dtype=torch.uint8, device="cuda")
+    d.view(torch.int64).random_(generator=g)
+    host = d.cpu().numpy()
+    got = dev_compute(gpu, t, bpc, d, chunk, nch, chunk)
+    assert nch * 65 >= 131072
+    assert got == oracle_chunks(t, bpc, host, chunk, nch, chunk)
