@@ -652,6 +652,10 @@ __global__ __launch_bounds__(kThreads) void crc_desc_kernel(const WindowDesc* de
 // parks those accumulators at the wrap, sums the head on fresh ones (the initial register belongs to the head),
 // and at the end advances the head's accumulators through the tail's length -- 3/4, 1/2 or 1/4 of a power-of-two
 // window: one or two of the power-of-two nibble operators -- and XORs the tail's in.  The fold is unchanged.
+//
+// Measured and not kept: issuing the loads of a wavefront's NEXT windows before the arithmetic of the current ones
+// (whole windows of 128 B to 2 KiB as one load group, two register buffers taking turns, 114 VGPRs, no spills) was
+// no faster at 128 / 256 B and 5-12 % slower from 512 B to 2 KiB: what these windows lack is not bytes in flight.
 template <int LPW, int MODE, int UNR, int PH>
 __global__ __launch_bounds__(kThreads) void crc_flat_kernel(const CrcLaunch p) {
   __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
@@ -807,6 +811,9 @@ __global__ __launch_bounds__(kThreads) void crc_flat_kernel(const CrcLaunch p) {
 #pragma unroll
       for (int k = 0; k < 8; k++) *va[k] ^= vt[k];
     }
+#ifdef OZCS_TUNE_NOFOLD  // timing-only build: what the loop and the loads cost without the per-window fold; results are wrong on purpose
+    uint32_t x = a.a0 ^ a.a1 ^ a.a2 ^ a.a3, y = b.a0 ^ b.a1 ^ b.a2 ^ b.a3;
+#else
     uint32_t x = slot_fold_chain(lds, za, a), y = slot_fold_chain(lds, zb, b);
 #pragma unroll
     for (int i = 0; i < kLevels; i++) {  // as in crc_subwave_kernel
@@ -816,6 +823,7 @@ __global__ __launch_bounds__(kThreads) void crc_flat_kernel(const CrcLaunch p) {
       x ^= t;
       y ^= lanes_up(t, i);
     }
+#endif
     if (sl == LPW - 1) {
       if (MODE == kModeCompute) {  // sums is 4-byte aligned in this layout (checked by the launcher)
         uint32_t* out = reinterpret_cast<uint32_t*>(p.sums);
@@ -903,9 +911,13 @@ int crc_choose_group(uint64_t n_windows, uint32_t bpc, int num_cus) {
   // window-shares of work (n_windows * G ~ 2 x the chip's 4096 wavefronts) and is never 1 -- with one
   // wavefront per window the slowest wavefronts finish late (6.68 against 6.90 TB/s at 8192 windows).
   // A wavefront should also get at least ~8 KiB of a window.
+  // From four windows per wavefront of the chip on (16,384 windows of 1 MiB: the benchmark's batch) eight
+  // wavefronts per window are ahead again, for the kernel (7.147 against 7.105 TB/s, three alternating rounds;
+  // level at 8,192 windows, behind at 4,096) as for a bare read in the same pattern (7.14 against 7.06 TB/s).
   int g = 16;
   const uint64_t want_waves = (uint64_t)num_cus * kWaves;
   while (g > 2 && n_windows * (uint64_t)(g / 2) >= 2 * want_waves) g >>= 1;
+  if (n_windows >= 4 * want_waves) g = 8;
   while (g > 1 && (uint64_t)bpc < (uint64_t)g * 8192u) g >>= 1;
   return g;
 }
