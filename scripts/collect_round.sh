@@ -1,9 +1,11 @@
 #!/bin/bash
-# Copies the measurement summaries (files named r02_*) from gpurun_out/ into profiles/ (run here after
-# scripts/final_measure_r02.sh ran on the GPU box).
+# Copies the measurement summaries (files named <round>_*) from gpurun_out/ into profiles/ and rebuilds
+# profiles/pmc_summary.json from the rocprofv3 passes (run here after scripts/final_measure.sh ran on the GPU box).
 set -eu
-for f in r02_configs.log r02_crc_window_sizes.log r02_pipeline_end_to_end.log r02_host_sync_calls.log r02_call_latency.log \
-         r02_small_chunk_batches.log r02_bench_default.json; do
+R=${ROUND:-r03}
+export ROUND=$R
+for f in ${R}_configs.log ${R}_crc_window_sizes.log ${R}_pipeline_end_to_end.log ${R}_host_sync_calls.log ${R}_call_latency.log \
+         ${R}_small_chunk_batches.log ${R}_bench_default.json; do
   if [ -f gpurun_out/$f ]; then cp gpurun_out/$f profiles/$f; fi   # the bench line is taken last, after a first collect
 done
 MIB=1048576

@@ -1,12 +1,14 @@
 #!/bin/bash
 # rocprofv3 passes over one bench.py configuration on the GPU box: a kernel-trace/stats pass, then PMC passes, one
-# counter block per run (never combined with a trace).  usage: TAG=name scripts/profile_r02.sh <bench.py arguments>
+# counter block per run (never combined with a trace).  usage: TAG=name scripts/profile_config.sh <bench.py arguments>
 # Output under gpurun_out/prof_<TAG>_*; scripts/summarize_pmc.py turns it into profiles/ entries.
 set -u
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out
 TAG=${TAG:-headline}
-BENCH="python3 $PWD/bench.py --no-cpu-baseline $*"
+# no child processes under the profiler (its preloaded library has initialised the GPU before python starts): the
+# bare-read ceiling, which bench.py measures in a child, is switched off here
+BENCH="python3 $PWD/bench.py --no-cpu-baseline --no-ceiling $*"
 cd /tmp
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_trace -- $BENCH > $OUT/prof_${TAG}_trace.log 2>&1 || exit 1
 for pass in "FETCH_SIZE" "WRITE_SIZE" \

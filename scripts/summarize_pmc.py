@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turns the rocprofv3 output of scripts/profile_r02.sh (gpurun_out/prof_<TAG>_*) into an entry of
+"""Turns the rocprofv3 output of scripts/profile_config.sh (gpurun_out/prof_<TAG>_*) into an entry of
 profiles/pmc_summary.json and a kernel-stats CSV under profiles/.
 
     scripts/summarize_pmc.py TAG KEY KERNEL_SUBSTRING ALGORITHMIC_BYTES [WARMUP_LAUNCHES [WAVE_BLOCKS]]
@@ -41,7 +41,7 @@ def kernel_times():
     launches from the kernel trace)."""
     avg_ns, calls, warm = None, 0, None
     for f in glob.glob(os.path.join(OUT, "prof_%s_trace" % TAG, "**", "*kernel_stats.csv"), recursive=True):
-        shutil.copy(f, os.path.join(ROOT, "profiles", "r02_kernel_stats_%s.csv" % TAG))
+        shutil.copy(f, os.path.join(ROOT, "profiles", "%s_kernel_stats_%s.csv" % (os.environ.get("ROUND", "r03"), TAG)))
         for r in csv.DictReader(open(f)):
             if KERNEL in r["Name"]:
                 avg_ns, calls = float(r["AverageNs"]), int(r["Calls"])
@@ -59,8 +59,8 @@ def main():
     kernel, c = counters()
     avg_ns, calls, warm_ns = kernel_times()
     rec = {
-        "command": "scripts/profile_r02.sh (rocprofv3 --kernel-trace --stats; --pmc, one block per run) -- python3 bench.py "
-                   "--no-cpu-baseline ...",
+        "command": "scripts/profile_config.sh (rocprofv3 --kernel-trace --stats; --pmc, one block per run) -- python3 bench.py "
+                   "--no-cpu-baseline --no-ceiling ...",
         "source_hash": native.source_hash(),
         "kernel": kernel, "kernel_avg_ns_profiled": avg_ns, "kernel_calls_profiled": calls,
         "kernel_avg_ns_after_warmup": warm_ns, "warmup_launches_excluded": WARMUP,
