@@ -1,8 +1,14 @@
 // Asynchronous pinned pipeline (ozcs_pipe_*): pinned chunk slots whose host-to-device copy, kernel and digest
 // hand-over overlap across chunks.  See include/ozone_checksum.h for the contract.
 //
-// Streams.  Copies run on one stream, CRC kernels on a second (a kernel waits for its slot's copy through an
-// event), so the copy of chunk n+1 overlaps the kernel of chunk n.  Kernels write their digests straight into
+// Streams.  Copies alternate over four streams, CRC kernels run on a fifth (a kernel waits for its slot's copy
+// through an event), so the copy of chunk n+1 overlaps the kernel of chunk n.  Several copy streams because one
+// stream carries chunk-sized copies one after the other with a gap between them: measured on MI355X (PCIe Gen5
+// x16, pinned memory, 4 MiB pieces) bare copies move 50.3 GB/s on one stream and 56.7-57.1 GB/s alternating over
+// two or four, which is what the link gives to copies of any size (57.2-57.6 GB/s for 256 MiB pieces).  The pipe
+// itself (copy + event + kernel per chunk, CRC32 at 1 MiB windows) carries 46.6 GB/s with one copy stream, 50-55
+// with two and 53.4-56.8 with four or eight; three and six are worse for mixed CRC / MD5 traffic than one (the
+// runtime deals streams out over four hardware queues: GPU_MAX_HW_QUEUES), so the default is four.  Kernels write their digests straight into
 // the slot's pinned, device-visible digest buffer: there is no copy-back and no third stream, and a slot is
 // complete when the event behind its kernel fires.
 //
@@ -49,6 +55,7 @@ constexpr int kSlotBits = 12;  // ozcs_pipe_create caps n_slots at 4096
 constexpr int kSlotMask = (1 << kSlotBits) - 1;
 constexpr uint32_t kEpochMask = (1u << 18) - 1;
 constexpr int kMaxDigestStreams = 8;
+constexpr int kMaxCopyStreams = 8;
 
 struct Slot {
   uint8_t* h_data = nullptr;  // pinned, slot_bytes
@@ -56,6 +63,7 @@ struct Slot {
   uint8_t* h_sums = nullptr;  // pinned, sums_bytes; kernels write it through d_sums_alias
   uint8_t* d_sums_alias = nullptr;  // device-side address of h_sums
   hipEvent_t copied = nullptr, done = nullptr;
+  int copy_stream = 0;  // which copy stream carried (or carries) this tenancy's bytes
   int state = kFree;
   bool deferred = false;  // digest slot parked for a batch
   int batch = -1;         // digest stream whose running batch hashes this slot (launched digest slots)
@@ -115,6 +123,8 @@ std::atomic<int> g_digest_launches{0};
 const int g_digest_streams = getenv("OZCS_PIPE_DIGEST_STREAMS") ? atoi(getenv("OZCS_PIPE_DIGEST_STREAMS")) : 2;
 // ... and whether they are created with the lowest stream priority (default) or the normal one (0).
 const int g_digest_low_prio = getenv("OZCS_PIPE_DIGEST_LOW_PRIO") ? atoi(getenv("OZCS_PIPE_DIGEST_LOW_PRIO")) : 1;
+// ... and the number of copy streams the slots' host-to-device copies alternate over (default 4, see above).
+const int g_copy_streams = getenv("OZCS_PIPE_COPY_STREAMS") ? atoi(getenv("OZCS_PIPE_COPY_STREAMS")) : 4;
 
 }  // namespace
 
@@ -122,7 +132,10 @@ struct ozcs_pipe {
   int device = 0;
   DeviceInfo dev;
   uint64_t slot_bytes = 0, sums_bytes = 0;
-  hipStream_t s_h2d = nullptr, s_kernel = nullptr;
+  hipStream_t s_h2d[kMaxCopyStreams] = {};
+  int n_copy = 1;          // copy streams in use
+  uint32_t next_copy = 0;  // round-robin position
+  hipStream_t s_kernel = nullptr;
   std::vector<DigestStream> digest;
   uint8_t* h_data_all = nullptr;
   uint8_t* d_data_all = nullptr;
@@ -258,7 +271,10 @@ int launch_deferred(ozcs_pipe* p, bool force = false) {
     uint32_t n_jobs = 0, n_windows = 0;
     d.slots.clear();
     size_t keep = 0;
-    int newest = -1;  // the batch's most recently submitted slot: copies are queued in submission order
+    // the batch's most recently submitted slot on each copy stream: a stream carries its copies in submission order,
+    // so the batch waits for these and has all its bytes
+    int newest[kMaxCopyStreams];
+    for (int& x : newest) x = -1;
     for (size_t i = 0; i < p->deferred.size(); i++) {
       const int t = p->deferred[i];
       Slot& s = p->slots[t];
@@ -274,10 +290,12 @@ int launch_deferred(ozcs_pipe* p, bool force = false) {
       j.first_window = n_windows;
       n_windows += (uint32_t)s.n_sums;
       d.slots.push_back(t);
-      newest = t;
+      newest[s.copy_stream] = t;
     }
     p->deferred.resize(keep);
-    hipError_t e = hipStreamWaitEvent(d.stream, p->slots[newest].copied, 0);
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < p->n_copy; k++)
+      if (newest[k] >= 0 && e == hipSuccess) e = hipStreamWaitEvent(d.stream, p->slots[newest[k]].copied, 0);
     if (e == hipSuccess) {
       const int k = g_digest_launches.fetch_add(1, std::memory_order_relaxed) + 1;
       e = (g_fault_digest_launch && k == g_fault_digest_launch) ? hipErrorLaunchFailure
@@ -356,7 +374,8 @@ hipError_t wait_progress(ozcs_pipe* p, std::unique_lock<std::mutex>& lk, hipEven
 
 void destroy_pipe(ozcs_pipe* p) {
   DeviceGuard dg(p->device);
-  if (p->s_h2d) (void)hipStreamSynchronize(p->s_h2d);
+  for (hipStream_t st : p->s_h2d)
+    if (st) (void)hipStreamSynchronize(st);
   if (p->s_kernel) (void)hipStreamSynchronize(p->s_kernel);
   for (DigestStream& d : p->digest)
     if (d.stream) (void)hipStreamSynchronize(d.stream);
@@ -373,7 +392,8 @@ void destroy_pipe(ozcs_pipe* p) {
   if (p->h_data_all) (void)hipHostFree(p->h_data_all);
   if (p->d_data_all) (void)hipFree(p->d_data_all);
   if (p->h_sums_all) (void)hipHostFree(p->h_sums_all);
-  if (p->s_h2d) (void)hipStreamDestroy(p->s_h2d);
+  for (hipStream_t st : p->s_h2d)
+    if (st) (void)hipStreamDestroy(st);
   if (p->s_kernel) (void)hipStreamDestroy(p->s_kernel);
   delete p;
 }
@@ -509,7 +529,10 @@ static int pipe_create_impl(int device, uint32_t n_slots, uint64_t slot_bytes, o
   }
   int prio_low = 0, prio_high = 0;  // numerically: low priority is the larger value
   (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
-  hipError_t e = hipStreamCreateWithFlags(&p->s_h2d, hipStreamNonBlocking);
+  p->n_copy = g_copy_streams < 1 ? 1 : g_copy_streams > kMaxCopyStreams ? kMaxCopyStreams : g_copy_streams;
+  hipError_t e = hipSuccess;
+  for (int k = 0; k < p->n_copy; k++)
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->s_h2d[k], hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->s_kernel, hipStreamNonBlocking);
   for (DigestStream& d : p->digest) {
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&d.stream, hipStreamNonBlocking, g_digest_low_prio ? prio_low : 0);
@@ -669,8 +692,9 @@ static int pipe_submit_slot_impl(ozcs_pipe* p, int ticket, int type, uint32_t bp
   int rc = OZCS_OK;
   const bool digest = n && (type == OZCS_SHA256 || type == OZCS_MD5);
   if (n) {
-    e = hipMemcpyAsync(s.d_data, s.h_data, len, hipMemcpyHostToDevice, p->s_h2d);
-    if (e == hipSuccess) e = hipEventRecord(s.copied, p->s_h2d);
+    s.copy_stream = (int)(p->next_copy++ % (uint32_t)p->n_copy);
+    e = hipMemcpyAsync(s.d_data, s.h_data, len, hipMemcpyHostToDevice, p->s_h2d[s.copy_stream]);
+    if (e == hipSuccess) e = hipEventRecord(s.copied, p->s_h2d[s.copy_stream]);
   }
   if (digest && e == hipSuccess) {
     s.deferred = true;
@@ -693,7 +717,7 @@ static int pipe_submit_slot_impl(ozcs_pipe* p, int ticket, int type, uint32_t bp
   if (e == hipSuccess && rc == OZCS_OK) e = hipEventRecord(s.done, p->s_kernel);
   if (e != hipSuccess) rc = fail_hip(e, "pipe submit");
   if (rc != OZCS_OK) {
-    (void)hipStreamSynchronize(p->s_h2d);
+    for (int k = 0; k < p->n_copy; k++) (void)hipStreamSynchronize(p->s_h2d[k]);
     (void)hipStreamSynchronize(p->s_kernel);
     return reject(rc);
   }

@@ -154,6 +154,15 @@ def main():
         g, backlog = run_in_order(L, 64, 4096, False, False, MIB)
         print(json.dumps({"types": "CRC32", "slots": 64, "harvest": "in-order pipe", "GBps": round(g, 2)}), flush=True)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "copy-streams":   # the workloads scripts/sweep_pipe_copy_streams.sh compares
+        print(json.dumps({"types": "CRC32", "slots": 16, "harvest": "oldest first", "GBps": round(run(L, 16, 4096, False, False, MIB, False), 2)}), flush=True)
+        print(json.dumps({"types": "CRC32", "slots": 16, "harvest": "oldest first", "input": "memcpy into the slot", "GBps": round(run(L, 16, 4096, False, True, MIB, False), 2)}), flush=True)
+        print(json.dumps({"types": "CRC32", "slots": 64, "harvest": "in-order pipe", "GBps": round(run_in_order(L, 64, 4096, False, False, MIB)[0], 2)}), flush=True)
+        print(json.dumps({"types": "CRC32:MD5 3:1", "slots": 64, "harvest": "any completed", "GBps": round(run(L, 64, 4096, True, False, MIB, True), 2)}), flush=True)
+        print(json.dumps({"types": "CRC32:MD5 3:1", "slots": 128, "harvest": "in-order pipe", "GBps": round(run_in_order(L, 128, 4096, True, False, MIB)[0], 2)}), flush=True)
+        print(json.dumps({"types": "CRC32:MD5 3:1", "slots": 256, "harvest": "in-order pipe", "GBps": round(run_in_order(L, 256, 8192, True, False, MIB)[0], 2)}), flush=True)
+        print(json.dumps({"types": "CRC32:MD5 3:1", "slots": 64, "bytes_per_checksum": 16384, "harvest": "oldest first", "GBps": round(run(L, 64, 4096, True, False, 16384, False), 2)}), flush=True)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "mix":   # quick look: CRC32:MD5 3:1 at 1 MiB windows only
         for slots in (64, 128):
             print(json.dumps({"slots": slots, "any_order_GBps": round(run(L, slots, 4096, True, False, MIB, True), 2)}), flush=True)
@@ -165,7 +174,7 @@ def main():
             (True, False, 16, MIB, False), (True, False, 64, MIB, False), (True, False, 128, MIB, False),
             (True, False, 256, MIB, False),
             (True, False, 16, MIB, True), (True, False, 32, MIB, True), (True, False, 64, MIB, True),
-            (True, False, 128, MIB, True), (True, True, 128, MIB, True),
+            (True, False, 96, MIB, True), (True, False, 128, MIB, True), (True, False, 256, MIB, True), (True, True, 128, MIB, True),
             (True, False, 16, 16384, False), (True, False, 64, 16384, False), (True, True, 64, 16384, False),
             (True, False, 64, 16384, True)):
         gbps = run(L, slots, 4096, mix, staged, bpc, any_order)
