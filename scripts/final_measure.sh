@@ -6,12 +6,7 @@ set -u
 O=gpurun_out
 R=${ROUND:-r03}
 export ROUND=$R
-bash scripts/run_configs.sh > $O/${R}_configs.log 2>&1 || exit 1
-bash scripts/crc_configs.sh > $O/${R}_crc_window_sizes.log 2>&1 || exit 1
-timeout -k 10 400 python -u scripts/bench_pipeline.py 2>/dev/null > $O/${R}_pipeline_end_to_end.log || exit 1
-timeout -k 10 300 python -u scripts/bench_host_sync.py 2>/dev/null > $O/${R}_host_sync_calls.log || exit 1
-timeout -k 10 300 python -u scripts/bench_latency.py 2>/dev/null > $O/${R}_call_latency.log || exit 1
-timeout -k 10 300 python -u scripts/bench_small_batch.py 2>/dev/null > $O/${R}_small_chunk_batches.log || exit 1
+# rocprofv3 passes first, and their summary: every bench line after them carries the measured traffic of these very sources
 TAG=headline bash scripts/profile_config.sh --steps 30 --warmup 10 > $O/prof_headline.log 2>&1 || exit 1
 TAG=cfg3 bash scripts/profile_config.sh --type CRC32C --bpc 16384 --mode verify --steps 20 --warmup 5 > $O/prof_cfg3.log 2>&1 || exit 1
 TAG=cfg4 bash scripts/profile_config.sh --type SHA256 --blocks 128 --steps 3 --warmup 1 > $O/prof_cfg4.log 2>&1 || exit 1
@@ -19,7 +14,12 @@ TAG=sha16k bash scripts/profile_config.sh --type SHA256 --bpc 16384 --blocks 32 
 TAG=md516k bash scripts/profile_config.sh --type MD5 --bpc 16384 --blocks 32 --steps 3 --warmup 1 > $O/prof_md516k.log 2>&1 || exit 1
 TAG=flat512 bash scripts/profile_config.sh --type CRC32 --bpc 512 --steps 8 --warmup 2 > $O/prof_flat512.log 2>&1 || exit 1
 TAG=flat16k bash scripts/profile_config.sh --type CRC32 --bpc 16384 --steps 8 --warmup 2 > $O/prof_flat16k.log 2>&1 || exit 1
-# the PMC record of these very sources first, so that the default bench line can carry the measured traffic
 bash scripts/collect_round.sh > $O/collect.log 2>&1 || exit 1
+bash scripts/run_configs.sh > $O/${R}_configs.log 2>&1 || exit 1
+bash scripts/crc_configs.sh > $O/${R}_crc_window_sizes.log 2>&1 || exit 1
+timeout -k 10 400 python -u scripts/bench_pipeline.py 2>/dev/null > $O/${R}_pipeline_end_to_end.log || exit 1
+timeout -k 10 300 python -u scripts/bench_host_sync.py 2>/dev/null > $O/${R}_host_sync_calls.log || exit 1
+timeout -k 10 300 python -u scripts/bench_latency.py 2>/dev/null > $O/${R}_call_latency.log || exit 1
+timeout -k 10 300 python -u scripts/bench_small_batch.py 2>/dev/null > $O/${R}_small_chunk_batches.log || exit 1
 timeout -k 10 200 python -u bench.py > $O/${R}_bench_default.json 2>/dev/null || exit 1
 echo final measure done
