@@ -387,6 +387,43 @@ def test_java_side_declines_without_touching_anything(jvm, java):
     assert not jvm.pending()
 
 
+@pytest.mark.gpu
+def test_reference_TestChecksum_shapes_through_the_java_route(jvm, java):
+    # TestChecksum.java:47-80 as the patched Checksum would run it: computeChecksum(byte[]) -> read-only heap view ->
+    # iterate(bytesPerChecksum) -> GpuChecksum.computeWindows; verifyChecksum(byte[], ChecksumData) recomputes the same
+    # way and compares with ChecksumData.verifyChecksumDataMatches.  55 alphabetic bytes at bytesPerChecksum 10 give
+    # exactly 6 checksums (:47-62); changing data[50] changes the ChecksumData and fails verification at index 5 (:67-80).
+    import oracle
+    from hadoop_ozone_amd import ChecksumData, ChecksumType, OzoneChecksumException
+    from java_side import JBuffer
+    rng = np.random.default_rng(2020)
+    data = rng.integers(ord("a"), ord("z") + 1, 55, dtype=np.uint8)           # RandomStringUtils.randomAlphabetic(55)
+
+    def compute(t, bpc, arr):      # Checksum.computeChecksum(byte[]) with the one-hunk patch applied
+        windows = _windows_of(JBuffer(arr, read_only=True), bpc)
+        out = []
+        assert java.computeWindows(int(t), bpc, windows, out)
+        return ChecksumData(t, bpc, out)
+
+    for t in (ChecksumType.SHA256, ChecksumType.CRC32, ChecksumType.CRC32C, ChecksumType.MD5):   # SHA256 is the test's default (:33-34)
+        cd = compute(t, 10, data)
+        assert len(cd.getChecksums()) == 6
+        assert b"".join(cd.getChecksums()) == oracle.compute(int(t), 10, data)
+        assert cd.verifyChecksumDataMatches(compute(t, 10, data), 0) is True                  # verifyChecksum(data, cd) (:60-61)
+        bad = data.copy()
+        bad[50] = ord("A") if bad[50] != ord("A") else ord("B")
+        other = compute(t, 10, bad)
+        assert other != cd and other.getChecksums()[:5] == cd.getChecksums()[:5]
+        with pytest.raises(OzoneChecksumException, match="Checksum mismatch at index 5"):
+            cd.verifyChecksumDataMatches(other, 0)
+    # TestChecksumImplsComputeSameValues.java:39-41 window sizes over one buffer, both CRCs, through the same route
+    big = oracle.splitmix64(64, 6 << 20)
+    for bpc in (512, 1024, 2048, 4096, 32768, 1048576):
+        for t in (ChecksumType.CRC32, ChecksumType.CRC32C):
+            assert b"".join(compute(t, bpc, big).getChecksums()) == oracle.compute(int(t), bpc, big), (bpc, t)
+    assert not jvm.pending()
+
+
 def _stats():
     from hadoop_ozone_amd import native
     return native.stats()
