@@ -15,6 +15,8 @@ import org.apache.ratis.thirdparty.com.google.protobuf.ByteString;
 public final class GpuChecksum {
   private static final boolean AVAILABLE;
 
+  /** Bit i = HIP device i; 0 = every gfx950 device of the node.  One JVM per GPU sets its own card's bit. */
+  private static final int DEVICE_MASK = Integer.getInteger("ozone.gpu.checksum.device.mask", 0);
   /** Calls with fewer bytes than this stay on the Java engines (one PCIe round trip costs more than a small CRC). */
   private static final long MIN_BYTES = Long.getLong("ozone.gpu.checksum.min.bytes", 0L);
   /** Geometry of the process-wide pinned pipe that carries non-direct buffers to the GPU. */
@@ -34,7 +36,7 @@ public final class GpuChecksum {
     boolean ok = false;
     try {
       System.loadLibrary("ozcs_jni");   // links libozcs.so
-      ok = nativeAvailable();
+      ok = nativeAvailable(DEVICE_MASK);
     } catch (UnsatisfiedLinkError e) {
       ok = false;                         // no library on java.library.path: keep the Java engines
     }
@@ -318,5 +320,5 @@ public final class GpuChecksum {
   public static native long pipeNextInOrder(long pipe, boolean block, int[] ticketStatusOut);
   public static native ByteBuffer pipeAcquireWait(long pipe, int[] ticketOut);
 
-  private static native boolean nativeAvailable();
+  private static native boolean nativeAvailable(int deviceMask);
 }

@@ -33,8 +33,11 @@ static void make_pipe(void) {
   if (ozcs_pipe_create(0, SHIM_SLOTS, SHIM_SLOT_BYTES, &g_pipe) != OZCS_OK) g_pipe = NULL;
 }
 
-JNIEXPORT jboolean JNICALL JFN(nativeAvailable)(JNIEnv* env, jclass cls) {
+/* deviceMask: bit i = HIP device i, 0 = every gfx950 device of the node (ozcs_init's argument).  A JVM that is one of
+ * several per node passes its own card's bit, so that it opens no context on the others. */
+JNIEXPORT jboolean JNICALL JFN(nativeAvailable)(JNIEnv* env, jclass cls, jint deviceMask) {
   (void)env; (void)cls;
+  if (deviceMask != 0 && ozcs_init((uint32_t)deviceMask) != OZCS_OK) return JNI_FALSE;
   return ozcs_available() ? JNI_TRUE : JNI_FALSE;
 }
 

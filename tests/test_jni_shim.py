@@ -76,7 +76,7 @@ class FakeJvm:
         self.env = L.fake_env()
         self.keep = []
         V, I, J, B = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint8
-        sig = {"nativeAvailable": (B, []),
+        sig = {"nativeAvailable": (B, [I]),
                "calculateChunkedSumsByteArray": (J, [I, I, V, I, V, I, I]),
                "calculateChunkedSumsDirect": (J, [I, I, V, I, I, V, I, I]),
                "verifyChunkedSumsByteArray": (J, [I, I, V, I, I, I, V, I, I]),
@@ -116,7 +116,7 @@ def jvm():
 @pytest.mark.gpu
 def test_shim_heap_arrays_through_its_pinned_pipe_and_beyond_a_slot(jvm):
     import oracle
-    assert jvm.nativeAvailable() == 1
+    assert jvm.nativeAvailable(0) == 1
     for t, ds in ((oracle.CRC32, 4), (oracle.CRC32C, 4), (oracle.SHA256, 32), (oracle.MD5, 16)):
         for n, bpc, off in ((4 << 20, 1 << 20, 0), (100000, 16384, 7), (12 << 20, 1 << 20, 3), (1, 512, 0)):
             if ds > 4 and n > (4 << 20):
