@@ -9,9 +9,13 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <emmintrin.h>
+
 #include <atomic>
 #include <mutex>
 #include <new>
+#include <chrono>
+#include <cstdio>
 #include <string>
 #include <thread>
 #include <vector>
@@ -165,6 +169,8 @@ static void destroy_ctx(HostCtx* c) {
   if (c->h_sums) (void)hipHostFree(c->h_sums);
   for (hipEvent_t ev : c->phase)
     if (ev) (void)hipEventDestroy(ev);
+  if (c->side_done) (void)hipEventDestroy(c->side_done);
+  if (c->side) (void)hipStreamDestroy(c->side);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -379,6 +385,68 @@ constexpr uint64_t kSplitCallBytes = 32ull << 20;  // ozcs_compute on at least t
 constexpr uint64_t kMaxLaunchWindows = 0x7fffffffull;  // window indices of a digest job launch are 32-bit
 constexpr size_t kGatherThreads = 4;
 constexpr uint64_t kGatherBytesPerThread = 8ull << 20;  // below 16 MiB of staged data one thread gathers
+constexpr uint64_t kSideCopyMinBytes = 32ull << 20;     // staged data from which a second copy stream is worth its event
+constexpr uint64_t kGatherNtMinBytes = 8ull << 20;      // staged data from which the gather writes around the cache
+
+// Wall-clock trace of one batch group's host phases, for tuning builds only (-DOZCS_TUNE_TRACE): one stderr line per group.
+struct BatchTrace {
+#ifdef OZCS_TUNE_TRACE
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
+  std::string line;
+  void lap(const char* what) {
+    const auto now = std::chrono::steady_clock::now();
+    char buf[64];
+    snprintf(buf, sizeof buf, " %s=%lldus", what, (long long)std::chrono::duration_cast<std::chrono::microseconds>(now - last).count());
+    line += buf;
+    last = now;
+  }
+  ~BatchTrace() {
+    fprintf(stderr, "[ozcs batch]%s total=%lldus\n", line.c_str(),
+            (long long)std::chrono::duration_cast<std::chrono::microseconds>(last - t0).count());
+  }
+#else
+  void lap(const char*) {}
+#endif
+};
+
+// Copy of one chunk into pinned staging with non-temporal stores: the staged bytes are read next by the copy engine,
+// not by a core, and the C library's memcpy takes ordinary stores below a few MiB -- every destination line is then
+// read into the cache before it is overwritten, which halves what a gathering thread moves when chunks are small.
+// dst is 16-byte aligned (staging offsets are multiples of 256).  The caller fences before the bytes are handed on.
+static void gather_copy(uint8_t* dst, const uint8_t* src, size_t n, bool streaming) {
+  if (!streaming || n < 256 || (reinterpret_cast<uintptr_t>(dst) & 15)) {
+    memcpy(dst, src, n);
+    return;
+  }
+  size_t i = 0;
+  for (; i + 64 <= n; i += 64) {
+    const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i));
+    const __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i + 16));
+    const __m128i c = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i + 32));
+    const __m128i d = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i + 48));
+    _mm_stream_si128(reinterpret_cast<__m128i*>(dst + i), a);
+    _mm_stream_si128(reinterpret_cast<__m128i*>(dst + i + 16), b);
+    _mm_stream_si128(reinterpret_cast<__m128i*>(dst + i + 32), c);
+    _mm_stream_si128(reinterpret_cast<__m128i*>(dst + i + 48), d);
+  }
+  if (i < n) memcpy(dst + i, src + i, n - i);
+}
+
+static bool gather_streaming_enabled() {  // OZCS_GATHER_NT=0: the C library's memcpy, for comparison
+  static const bool on = [] {
+    const char* v = getenv("OZCS_GATHER_NT");
+    return !(v && v[0] == '0');
+  }();
+  return on;
+}
+
+static bool batch_side_copy_enabled() {
+  static const bool on = [] {
+    const char* v = getenv("OZCS_BATCH_SIDE_COPY");
+    return !(v && v[0] == '0');
+  }();
+  return on;
+}
 
 static void batch_on_device(int device, ozcs_chunk* chunks, uint32_t lo, uint32_t hi) {
   auto fail_all = [&](uint32_t a, uint32_t b, int code) {
@@ -390,11 +458,15 @@ static void batch_on_device(int device, ozcs_chunk* chunks, uint32_t lo, uint32_
   if (!dg.ok()) return fail_all(lo, hi, fail(OZCS_ENODEV, "cannot select device %d", device));
   HostCtx* c = acquire_ctx(device);
   if (!c) return fail_all(lo, hi, fail(OZCS_EHIP, "cannot create a stream on device %d", device));
-  struct Item { uint32_t idx; uint64_t data_off, sums_off, n; size_t ds; bool staged, small; };
+  // run: on the first of consecutive CRC chunks of one shape (type, window size, length) that are laid out back to back,
+  // the number of chunks one launch covers; 0 on the chunks that follow it and on everything that has no launch of its
+  // own (digest chunks, and small chunks, which share a launch through window descriptors unless they form a run)
+  struct Item { uint32_t idx; uint64_t data_off, sums_off, n; size_t ds; bool staged, small; uint32_t run; };
   const int kTypes[4] = {OZCS_CRC32, OZCS_CRC32C, OZCS_SHA256, OZCS_MD5};
   uint32_t i = lo;
   while (i < hi) {
     // ---- pick a group that fits the staging budget, validating as we go ----
+    BatchTrace trace;
     std::vector<Item> items;
     uint64_t group_bytes = 0;
     uint32_t j = i;
@@ -412,30 +484,59 @@ static void batch_on_device(int device, ozcs_chunk* chunks, uint32_t lo, uint32_
         continue;
       }
       if (!items.empty() && group_bytes + ch.len > kBatchStageBytes) break;
-      items.push_back(Item{j, 0, 0, n, ds, ch.len <= kStagedChunkBytes, ch.len <= kSmallChunkBytes && n <= kSmallChunkWindows});
+      items.push_back(Item{j, 0, 0, n, ds, ch.len <= kStagedChunkBytes, ch.len <= kSmallChunkBytes && n <= kSmallChunkWindows, 0});
       group_bytes += (ch.len + 255) & ~(uint64_t)255;
     }
     const uint32_t group_end = j;
     if (!items.empty()) {
-      // ---- layout: staged chunks first (one contiguous region), then the others ----
+      // ---- layout: staged chunks first (one contiguous region), then the others; digests in the same order.
+      // CRC chunks of one shape that follow each other get their digests back to back, so that one launch covers
+      // the whole run (a launch per 4 MiB chunk keeps a fraction of the chip busy for 15-25 us each, after the
+      // last copy has landed). ----
       uint64_t data_bytes = 0, sums_bytes = 0, n_desc = 0, n_jobs = 0, staged_bytes = 0;
-      for (int pass = 0; pass < 2; pass++) {
-        for (Item& it : items) {
-          if (it.staged != (pass == 0)) continue;
-          it.data_off = data_bytes;
-          data_bytes += (chunks[it.idx].len + 255) & ~(uint64_t)255;
-          if (it.small) n_desc += it.n;
-          else if (chunks[it.idx].type == OZCS_SHA256 || chunks[it.idx].type == OZCS_MD5) n_jobs++;
+      std::vector<Item*> order;
+      order.reserve(items.size());
+      for (int pass = 0; pass < 2; pass++)
+        for (Item& it : items)
+          if (it.staged == (pass == 0)) order.push_back(&it);
+      Item* head = nullptr;
+      for (Item* it : order) {  // runs first: whether a small chunk goes through the descriptor list depends on them
+        const ozcs_chunk& ch = chunks[it->idx];
+        const bool crc = ch.type == OZCS_CRC32 || ch.type == OZCS_CRC32C;
+        if (head && crc && chunks[head->idx].type == ch.type && chunks[head->idx].bpc == ch.bpc &&
+            chunks[head->idx].len == ch.len) {
+          head->run++;
+        } else {
+          head = crc ? it : nullptr;
+          if (head) head->run = 1;
         }
-        if (pass == 0) staged_bytes = data_bytes;
       }
+      uint32_t left = 0;  // chunks still to come in the run being laid out
+      for (Item* it : order) {
+        const ozcs_chunk& ch = chunks[it->idx];
+        const bool crc = ch.type == OZCS_CRC32 || ch.type == OZCS_CRC32C;
+        it->data_off = data_bytes;
+        data_bytes += (ch.len + 255) & ~(uint64_t)255;
+        if (it->staged) staged_bytes = data_bytes;
+        if (left) {  // inside a run: digests follow the previous chunk's
+          left--;
+          it->small = false;
+        } else {
+          if (it->small && it->run == 1) it->run = 0;  // a lone small chunk: one window descriptor per window
+          if (it->run > 1) it->small = false;          // equal small chunks: the uniform launch serves them better
+          sums_bytes = it->small ? ((sums_bytes + 31) & ~(uint64_t)31) : ((sums_bytes + 255) & ~(uint64_t)255);
+          left = it->run ? it->run - 1 : 0;
+        }
+        if (it->small) n_desc += it->n;
+        else if (!crc) n_jobs++;
+        it->sums_off = sums_bytes;
+        sums_bytes += it->n * it->ds;
+      }
+      sums_bytes = (sums_bytes + 255) & ~(uint64_t)255;
       // the pinned staging buffer and the device's auxiliary buffer both hold: window descriptors, then digest jobs
       const uint64_t desc_bytes = n_desc * sizeof(WindowDesc), aux_bytes = desc_bytes + n_jobs * sizeof(DigestJob);
-      for (Item& it : items) {
-        it.sums_off = sums_bytes;
-        sums_bytes += it.small ? ((it.n * it.ds + 31) & ~(uint64_t)31) : ((it.n * it.ds + 255) & ~(uint64_t)255);
-      }
       const bool pinned_sums = sums_bytes <= kPinnedSumsMax;
+      trace.lap("layout");
       int rc = ctx_reserve(&c->d_data, &c->data_cap, data_bytes);
       if (rc == OZCS_OK) rc = ctx_reserve(&c->d_sums, &c->sums_cap, sums_bytes);
       if (rc == OZCS_OK && aux_bytes) rc = ctx_reserve(&c->d_aux, &c->aux_cap, aux_bytes);
@@ -457,20 +558,33 @@ static void batch_on_device(int device, ozcs_chunk* chunks, uint32_t lo, uint32_
         std::vector<const Item*> staged;
         for (const Item& it : items)
           if (it.staged) staged.push_back(&it);
+        hipStream_t side = nullptr;
+        if (staged_bytes >= kSideCopyMinBytes && batch_side_copy_enabled()) {
+          if (!c->side && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) c->side = nullptr;
+          if (c->side && !c->side_done && hipEventCreateWithFlags(&c->side_done, hipEventDisableTiming) != hipSuccess)
+            c->side_done = nullptr;
+          if (c->side && c->side_done) side = c->side;
+        }
+        std::atomic<uint32_t> piece_no{0};
+        const bool nt_mode = staged_bytes >= kGatherNtMinBytes && gather_streaming_enabled();
+        auto send = [&](uint64_t from, uint64_t to) {
+          if (nt_mode) _mm_sfence();  // streaming stores are visible to the copy engine only after a fence
+          hipStream_t st = (side && (piece_no.fetch_add(1, std::memory_order_relaxed) & 1)) ? side : c->stream;
+          return hipMemcpyAsync(dd + from, hs + from, to - from, hipMemcpyHostToDevice, st);
+        };
         auto gather = [&](size_t a, size_t b, hipError_t* err) {
           DeviceGuard tg(device);
           uint64_t sent = staged[a]->data_off, end = sent;
           for (size_t q = a; q < b; q++) {
             const ozcs_chunk& ch = chunks[staged[q]->idx];
-            memcpy(hs + staged[q]->data_off, ch.data, ch.len);
+            gather_copy(hs + staged[q]->data_off, static_cast<const uint8_t*>(ch.data), ch.len, nt_mode);
             end = staged[q]->data_off + ((ch.len + 255) & ~(uint64_t)255);
             if (end - sent >= kStagePiece && *err == hipSuccess) {
-              *err = hipMemcpyAsync(dd + sent, hs + sent, end - sent, hipMemcpyHostToDevice, c->stream);
+              *err = send(sent, end);
               sent = end;
             }
           }
-          if (end > sent && *err == hipSuccess)
-            *err = hipMemcpyAsync(dd + sent, hs + sent, end - sent, hipMemcpyHostToDevice, c->stream);
+          if (end > sent && *err == hipSuccess) *err = send(sent, end);
         };
         size_t nthreads = (size_t)(staged_bytes / kGatherBytesPerThread);
         if (nthreads > kGatherThreads) nthreads = kGatherThreads;
@@ -502,12 +616,21 @@ static void batch_on_device(int device, ozcs_chunk* chunks, uint32_t lo, uint32_
           for (hipError_t x : errs)
             if (x != hipSuccess && e == hipSuccess) e = x;
         }
+        if (side) {  // the kernels follow every copy: the main stream takes the side stream's copies in
+          hipError_t x = hipEventRecord(c->side_done, side);
+          if (x == hipSuccess) x = hipStreamWaitEvent(c->stream, c->side_done, 0);
+          if (x != hipSuccess) {  // not ordered by the event: order by waiting
+            (void)hipStreamSynchronize(side);
+            if (e == hipSuccess) e = x;
+          }
+        }
       }
       // the other chunks' bytes: a copy each (they are too large to be worth staging)
       for (const Item& it : items)
         if (!it.staged && rc == OZCS_OK && e == hipSuccess)
           e = hipMemcpyAsync(dd + it.data_off, chunks[it.idx].data, chunks[it.idx].len, hipMemcpyHostToDevice, c->stream);
       timer.mark(1);
+      trace.lap("gather");
       if (rc == OZCS_OK && n_desc) {
         // ---- descriptors of the small chunks' windows, grouped by checksum type ----
         WindowDesc* hd = reinterpret_cast<WindowDesc*>(static_cast<uint8_t*>(c->h_stage) + staged_bytes);  // 256-aligned
@@ -543,7 +666,7 @@ static void batch_on_device(int device, ozcs_chunk* chunks, uint32_t lo, uint32_
           s_bytes.fetch_add(bytes[t], std::memory_order_relaxed);
         }
       }
-      // ---- the other chunks: digests through the job list, CRC one launch per chunk ----
+      // ---- the other chunks: digests through the job list, CRC one launch per run of equal chunks ----
       if (rc == OZCS_OK && e == hipSuccess && n_jobs) {
         // one job per chunk, grouped by algorithm; each group is one launch (more only where the windows of a
         // group pass what a launch can number)
@@ -579,12 +702,12 @@ static void batch_on_device(int device, ozcs_chunk* chunks, uint32_t lo, uint32_
           s_windows.fetch_add(run.n_windows, std::memory_order_relaxed);
         }
       }
-      for (const Item& it : items) {
-        const ozcs_chunk& ch = chunks[it.idx];
-        if (it.small || (ch.type != OZCS_CRC32 && ch.type != OZCS_CRC32C)) continue;
+      for (const Item* it : order) {
+        if (!it->run) continue;
+        const ozcs_chunk& ch = chunks[it->idx];
         if (rc == OZCS_OK && e == hipSuccess)
-          rc = launch_windows(*dev, ch.type, ch.bpc, dd + it.data_off, ch.len, 1, ch.len, kModeCompute,
-                              dsums + it.sums_off, nullptr, 0, 0, 0, nullptr, c->stream);
+          rc = launch_windows(*dev, ch.type, ch.bpc, dd + it->data_off, ch.len, it->run, (ch.len + 255) & ~(uint64_t)255,
+                              kModeCompute, dsums + it->sums_off, nullptr, 0, 0, 0, nullptr, c->stream);
       }
       timer.mark(2);
       // ---- digests back: one copy into pinned memory and a scatter, or a copy per chunk ----
@@ -598,7 +721,9 @@ static void batch_on_device(int device, ozcs_chunk* chunks, uint32_t lo, uint32_
         }
       }
       timer.mark(3);
+      trace.lap("enqueue");
       const hipError_t es = hipStreamSynchronize(c->stream);
+      trace.lap("sync");
       if (rc == OZCS_OK && e != hipSuccess) rc = fail_hip(e, "batch enqueue");
       if (rc == OZCS_OK && es != hipSuccess) rc = fail_hip(es, "hipStreamSynchronize");
       if (rc == OZCS_OK) timer.finish();
@@ -612,6 +737,7 @@ static void batch_on_device(int device, ozcs_chunk* chunks, uint32_t lo, uint32_
           s_d2h.fetch_add(it.n * it.ds, std::memory_order_relaxed);
         }
       }
+      trace.lap("scatter");
     }
     i = group_end;
   }

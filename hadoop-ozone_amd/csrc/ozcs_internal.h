@@ -33,6 +33,10 @@ struct HostCtx {
   size_t h_stage_cap = 0;
   void* h_sums = nullptr;
   size_t h_sums_cap = 0;
+  // second copy stream of the batched call's large gathers (every other staged piece goes through it: two copy
+  // queues fill the link, one does not quite), created on first use
+  hipStream_t side = nullptr;
+  hipEvent_t side_done = nullptr;
   // phase timing of sampled calls (PhaseTimer): events created on first use
   hipEvent_t phase[4] = {nullptr, nullptr, nullptr, nullptr};
 };

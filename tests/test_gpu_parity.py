@@ -742,6 +742,38 @@ def test_compute_batch_random_sweep(gpu):
         assert outs[i].raw == oracle.compute(t, bpc, bufs[i]), (i, t, bpc, ln)
 
 
+def test_compute_batch_runs_of_equal_chunks(gpu):
+    """Equal CRC chunks that follow each other share one launch inside ozcs_compute_batch: runs of small and of large
+    chunks, lengths that are no multiple of the 256-byte layout grain or of the window size, runs cut by another
+    shape, type or a digest chunk, a run of one, and a run spanning staged and unstaged sizes."""
+    torch, native, L = gpu
+    C, CC, S, M = oracle.CRC32, oracle.CRC32C, oracle.SHA256, oracle.MD5
+    plan = ([(C, 16384, 65536)] * 9 + [(C, 16384, 65537)] * 3 + [(M, 16384, 65536)] + [(C, 16384, 65536)] * 2 +
+            [(CC, 16384, 65536)] * 5 + [(CC, 4096, 65536)] * 4 + [(C, MIB, 4 * MIB)] * 6 + [(C, MIB, 4 * MIB - 100)] * 3 +
+            [(S, 65536, MIB)] + [(C, MIB, 4 * MIB)] + [(CC, 100000, 3 * MIB + 77)] * 4 + [(C, 512, 1000)] * 40 +
+            [(C, 512, 999)] + [(C, 512, 1000)] * 2 + [(C, MIB, 9 * MIB)] * 3 + [(C, 1, 300)] * 3 + [(CC, 1 << 20, 1)] * 5)
+    n = len(plan)
+    arr = (native.OzcsChunk * n)()
+    bufs, outs = [], []
+    for i, (t, bpc, ln) in enumerate(plan):
+        b = oracle.splitmix64(9100 + i, ln)
+        o = ctypes.create_string_buffer(((ln + bpc - 1) // bpc) * native.DIGEST_SIZE[t])
+        bufs.append(b)
+        outs.append(o)
+        arr[i].data, arr[i].len = b.ctypes.data, ln
+        arr[i].sums, arr[i].sums_cap = ctypes.cast(o, ctypes.c_void_p).value, len(o)
+        arr[i].bpc, arr[i].type = bpc, t
+    before = native.stats()
+    native.check(L.ozcs_compute_batch(arr, n))
+    after = native.stats()
+    for i, (t, bpc, ln) in enumerate(plan):
+        assert arr[i].status == native.OK and arr[i].n_sums == (ln + bpc - 1) // bpc, (i, t, bpc, ln)
+        assert outs[i].raw == oracle.compute(t, bpc, bufs[i]), (i, t, bpc, ln)
+    # 14 runs of CRC chunks (the 9 MiB chunks are laid out last), and three window-descriptor launches: the lone small
+    # CRC32 chunk (512, 999) and the MD5 and SHA-256 chunks
+    assert after["kernel_launches"] - before["kernel_launches"] == 14 + 3
+
+
 def test_full_size_properties_other_configurations(gpu):
     """The per-GPU share of the 16 KiB verify configuration (8 GiB, 524,288 windows) and the whole SHA-256
     configuration (32 GiB at 1 MiB windows, 32,768 windows): sampled windows against the oracle, permutation
