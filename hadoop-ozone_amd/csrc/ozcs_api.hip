@@ -11,7 +11,10 @@
 
 #include <emmintrin.h>
 
+#include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <chrono>
@@ -314,6 +317,148 @@ static int check_type_bpc(int type, uint32_t bpc) {
   return OZCS_OK;
 }
 
+// ---- gathers: caller memory into pinned staging, range by range, and on to the device ----
+constexpr uint64_t kStagePiece = 8ull << 20;            // largest byte range of a gather, and of one copy to the device
+constexpr size_t kGatherThreads = 4;                    // the caller and three helpers
+constexpr uint64_t kGatherRangeMin = 256ull << 10;      // smallest byte range one gather part copies and sends
+constexpr uint64_t kGatherNtMinBytes = 8ull << 20;      // staged data from which the gather writes around the cache
+
+// ---- helper threads of the gathers (host copies of caller memory into pinned staging) ----
+// A caller publishes a job of n parts and works through the parts itself; helpers that are awake claim parts beside
+// it.  Nobody waits for a helper to wake up: once every part is claimed, the caller only waits for the parts that
+// helpers have already taken.  With no helper at all (threads not to be had, a forked child) the caller does
+// every part.  Helpers are started on first use and joined by ozcs_shutdown and at process exit.
+class GatherPool {
+ public:
+  static GatherPool& get() {
+    static GatherPool pool;
+    return pool;
+  }
+  ~GatherPool() { stop(); }
+
+  void run(size_t n_parts, const std::function<void(size_t)>& fn) {
+    if (n_parts == 0) return;
+    if (n_parts == 1) return fn(0);
+    Job job{&fn, n_parts, 0, 0};
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      if (!started_) {
+        started_ = true;
+        for (size_t t = 0; t + 1 < kGatherThreads; t++) {
+          try {
+            helpers_.emplace_back([this] { helper_main(); });
+          } catch (...) {
+            break;
+          }
+        }
+      }
+      jobs_.push_back(&job);
+    }
+    work_.notify_all();
+    for (;;) {
+      size_t idx;
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (job.next >= job.n) break;
+        idx = claim(&job);
+      }
+      fn(idx);
+      std::lock_guard<std::mutex> lk(mu_);
+      job.done++;
+    }
+    std::unique_lock<std::mutex> lk(mu_);
+    done_.wait(lk, [&] { return job.done == job.n; });
+  }
+
+  void stop() {
+    std::vector<std::thread> joining;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stop_ = true;
+      joining.swap(helpers_);
+    }
+    work_.notify_all();
+    for (std::thread& t : joining) t.join();
+    std::lock_guard<std::mutex> lk(mu_);
+    stop_ = false;
+    started_ = false;
+  }
+
+ private:
+  struct Job {
+    const std::function<void(size_t)>* fn;
+    size_t n, next, done;
+  };
+  // under mu_: the next part of a job; a job with no part left is taken off the list
+  size_t claim(Job* job) {
+    const size_t idx = job->next++;
+    if (job->next == job->n) jobs_.erase(std::find(jobs_.begin(), jobs_.end(), job));
+    return idx;
+  }
+  void helper_main() {
+    std::unique_lock<std::mutex> lk(mu_);
+    for (;;) {
+      work_.wait(lk, [&] { return stop_ || !jobs_.empty(); });
+      if (stop_) return;
+      Job* job = jobs_.front();
+      const size_t idx = claim(job);
+      lk.unlock();
+      try {
+        (*job->fn)(idx);
+      } catch (...) {  // a part reports through what it writes; nothing may escape a helper
+      }
+      lk.lock();
+      if (++job->done == job->n) done_.notify_all();  // the job lives on its caller's stack until then
+    }
+  }
+
+  std::mutex mu_;
+  std::condition_variable work_, done_;
+  std::vector<Job*> jobs_;
+  std::vector<std::thread> helpers_;
+  bool started_ = false, stop_ = false;
+};
+
+// Copy of one chunk into pinned staging with non-temporal stores: the staged bytes are read next by the copy engine,
+// not by a core, and the C library's memcpy takes ordinary stores below a few MiB -- every destination line is then
+// read into the cache before it is overwritten, which halves what a gathering thread moves when chunks are small.
+// dst is 16-byte aligned (staging offsets are multiples of 256).  The caller fences before the bytes are handed on.
+static void gather_copy(uint8_t* dst, const uint8_t* src, size_t n, bool streaming) {
+  if (!streaming || n < 256 || (reinterpret_cast<uintptr_t>(dst) & 15)) {
+    memcpy(dst, src, n);
+    return;
+  }
+  size_t i = 0;
+  for (; i + 64 <= n; i += 64) {
+    const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i));
+    const __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i + 16));
+    const __m128i c = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i + 32));
+    const __m128i d = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i + 48));
+    _mm_stream_si128(reinterpret_cast<__m128i*>(dst + i), a);
+    _mm_stream_si128(reinterpret_cast<__m128i*>(dst + i + 16), b);
+    _mm_stream_si128(reinterpret_cast<__m128i*>(dst + i + 32), c);
+    _mm_stream_si128(reinterpret_cast<__m128i*>(dst + i + 48), d);
+  }
+  if (i < n) memcpy(dst + i, src + i, n - i);
+}
+
+static bool gather_streaming_enabled() {  // OZCS_GATHER_NT=0: the C library's memcpy, for comparison
+  static const bool on = [] {
+    const char* v = getenv("OZCS_GATHER_NT");
+    return !(v && v[0] == '0');
+  }();
+  return on;
+}
+
+// Size of the byte ranges a staged region of `bytes` is cut into: an eighth of it, between kGatherRangeMin and
+// kStagePiece, in whole 4 KiB.
+static uint64_t gather_range(uint64_t bytes) {
+  uint64_t range = (bytes / 8 + 4095) & ~(uint64_t)4095;
+  if (range < kGatherRangeMin) range = kGatherRangeMin;
+  if (range > kStagePiece) range = kStagePiece;
+  return range;
+}
+
 // Device for a single host-pointer call.  A caller thread keeps the device it was first given (threads are dealt
 // out round-robin): the callers are long-lived writer / reader / scanner threads, and staying put lets each reuse
 // the pooled staging buffers of its device instead of growing a set on every device in turn.
@@ -379,14 +524,10 @@ constexpr uint64_t kBatchStageBytes = 512ull << 20;  // also the most pinned mem
 constexpr uint64_t kStagedChunkBytes = 8ull << 20;
 constexpr uint64_t kSmallChunkBytes = 1ull << 20;
 constexpr uint64_t kSmallChunkWindows = 64;
-constexpr uint64_t kStagePiece = 8ull << 20;
 constexpr uint64_t kPinnedSumsMax = 32ull << 20;
 constexpr uint64_t kSplitCallBytes = 32ull << 20;  // ozcs_compute on at least this much goes through the batched path
 constexpr uint64_t kMaxLaunchWindows = 0x7fffffffull;  // window indices of a digest job launch are 32-bit
-constexpr size_t kGatherThreads = 4;
-constexpr uint64_t kGatherBytesPerThread = 8ull << 20;  // below 16 MiB of staged data one thread gathers
 constexpr uint64_t kSideCopyMinBytes = 32ull << 20;     // staged data from which a second copy stream is worth its event
-constexpr uint64_t kGatherNtMinBytes = 8ull << 20;      // staged data from which the gather writes around the cache
 
 // Wall-clock trace of one batch group's host phases, for tuning builds only (-DOZCS_TUNE_TRACE): one stderr line per group.
 struct BatchTrace {
@@ -408,37 +549,6 @@ struct BatchTrace {
   void lap(const char*) {}
 #endif
 };
-
-// Copy of one chunk into pinned staging with non-temporal stores: the staged bytes are read next by the copy engine,
-// not by a core, and the C library's memcpy takes ordinary stores below a few MiB -- every destination line is then
-// read into the cache before it is overwritten, which halves what a gathering thread moves when chunks are small.
-// dst is 16-byte aligned (staging offsets are multiples of 256).  The caller fences before the bytes are handed on.
-static void gather_copy(uint8_t* dst, const uint8_t* src, size_t n, bool streaming) {
-  if (!streaming || n < 256 || (reinterpret_cast<uintptr_t>(dst) & 15)) {
-    memcpy(dst, src, n);
-    return;
-  }
-  size_t i = 0;
-  for (; i + 64 <= n; i += 64) {
-    const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i));
-    const __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i + 16));
-    const __m128i c = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i + 32));
-    const __m128i d = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i + 48));
-    _mm_stream_si128(reinterpret_cast<__m128i*>(dst + i), a);
-    _mm_stream_si128(reinterpret_cast<__m128i*>(dst + i + 16), b);
-    _mm_stream_si128(reinterpret_cast<__m128i*>(dst + i + 32), c);
-    _mm_stream_si128(reinterpret_cast<__m128i*>(dst + i + 48), d);
-  }
-  if (i < n) memcpy(dst + i, src + i, n - i);
-}
-
-static bool gather_streaming_enabled() {  // OZCS_GATHER_NT=0: the C library's memcpy, for comparison
-  static const bool on = [] {
-    const char* v = getenv("OZCS_GATHER_NT");
-    return !(v && v[0] == '0');
-  }();
-  return on;
-}
 
 static bool batch_side_copy_enabled() {
   static const bool on = [] {
@@ -550,14 +660,16 @@ static void batch_on_device(int device, ozcs_chunk* chunks, uint32_t lo, uint32_
       PhaseTimer timer(c, group_bytes);
       timer.mark(0);
       if (rc == OZCS_OK && staged_bytes) {
-        // ---- gather the staged chunks; each finished piece starts its copy while the next is gathered.
-        // One thread's memcpy feeds about half of what the link takes, so large gathers are shared by up to
-        // kGatherThreads threads, each with a contiguous run of the staged items (copies of different
-        // pieces may be queued in any order: the kernels come after all of them on the same stream). ----
+        // ---- gather the staged chunks into pinned memory and copy it on, part by part.
+        // The staged region is cut into byte ranges (a chunk may straddle ranges); whoever takes a range copies the
+        // chunk bytes that fall into it and queues the range's copy to the device, so the link works while the rest
+        // is still being gathered.  One thread's copy feeds about half of what the link takes: the ranges are
+        // shared with the gather pool's helpers.  Ranges may be queued in any order: the kernels come after all of
+        // them. ----
         uint8_t* hs = static_cast<uint8_t*>(c->h_stage);
         std::vector<const Item*> staged;
-        for (const Item& it : items)
-          if (it.staged) staged.push_back(&it);
+        for (const Item* it : order)
+          if (it->staged) staged.push_back(it);
         hipStream_t side = nullptr;
         if (staged_bytes >= kSideCopyMinBytes && batch_side_copy_enabled()) {
           if (!c->side && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) c->side = nullptr;
@@ -565,57 +677,33 @@ static void batch_on_device(int device, ozcs_chunk* chunks, uint32_t lo, uint32_
             c->side_done = nullptr;
           if (c->side && c->side_done) side = c->side;
         }
-        std::atomic<uint32_t> piece_no{0};
         const bool nt_mode = staged_bytes >= kGatherNtMinBytes && gather_streaming_enabled();
-        auto send = [&](uint64_t from, uint64_t to) {
-          if (nt_mode) _mm_sfence();  // streaming stores are visible to the copy engine only after a fence
-          hipStream_t st = (side && (piece_no.fetch_add(1, std::memory_order_relaxed) & 1)) ? side : c->stream;
-          return hipMemcpyAsync(dd + from, hs + from, to - from, hipMemcpyHostToDevice, st);
-        };
-        auto gather = [&](size_t a, size_t b, hipError_t* err) {
+        const uint64_t range = gather_range(staged_bytes);
+        const size_t n_ranges = (size_t)((staged_bytes + range - 1) / range);
+        std::atomic<int> first_err{(int)hipSuccess};
+        auto gather = [&](size_t r) {
           DeviceGuard tg(device);
-          uint64_t sent = staged[a]->data_off, end = sent;
-          for (size_t q = a; q < b; q++) {
+          const uint64_t lo_b = r * range, hi_b = lo_b + range < staged_bytes ? lo_b + range : staged_bytes;
+          // first staged chunk that reaches into the range
+          size_t q = (size_t)(std::upper_bound(staged.begin(), staged.end(), lo_b,
+                                               [](uint64_t v, const Item* it) { return v < it->data_off; }) -
+                              staged.begin());
+          if (q) q--;
+          for (; q < staged.size() && staged[q]->data_off < hi_b; q++) {
             const ozcs_chunk& ch = chunks[staged[q]->idx];
-            gather_copy(hs + staged[q]->data_off, static_cast<const uint8_t*>(ch.data), ch.len, nt_mode);
-            end = staged[q]->data_off + ((ch.len + 255) & ~(uint64_t)255);
-            if (end - sent >= kStagePiece && *err == hipSuccess) {
-              *err = send(sent, end);
-              sent = end;
-            }
+            const uint64_t a = staged[q]->data_off > lo_b ? staged[q]->data_off : lo_b;
+            const uint64_t b = staged[q]->data_off + ch.len < hi_b ? staged[q]->data_off + ch.len : hi_b;
+            if (a < b)
+              gather_copy(hs + a, static_cast<const uint8_t*>(ch.data) + (a - staged[q]->data_off), b - a, nt_mode);
           }
-          if (end > sent && *err == hipSuccess) *err = send(sent, end);
+          if (nt_mode) _mm_sfence();  // streaming stores are visible to the copy engine only after a fence
+          const hipError_t x = hipMemcpyAsync(dd + lo_b, hs + lo_b, hi_b - lo_b, hipMemcpyHostToDevice,
+                                              (side && (r & 1)) ? side : c->stream);
+          int expect = (int)hipSuccess;
+          if (x != hipSuccess) first_err.compare_exchange_strong(expect, (int)x);
         };
-        size_t nthreads = (size_t)(staged_bytes / kGatherBytesPerThread);
-        if (nthreads > kGatherThreads) nthreads = kGatherThreads;
-        if (nthreads > staged.size()) nthreads = staged.size();
-        if (nthreads <= 1) {
-          gather(0, staged.size(), &e);
-        } else {
-          // split by bytes, not by item count
-          std::vector<size_t> cut(nthreads + 1, staged.size());
-          cut[0] = 0;
-          size_t q = 0;
-          for (size_t t = 1; t < nthreads; t++) {
-            const uint64_t target = staged_bytes * t / nthreads;
-            while (q < staged.size() && staged[q]->data_off < target) q++;
-            cut[t] = q;
-          }
-          std::vector<hipError_t> errs(nthreads, hipSuccess);
-          std::vector<std::thread> th;
-          for (size_t t = 1; t < nthreads; t++) {
-            if (cut[t] >= cut[t + 1]) continue;
-            try {
-              th.emplace_back(gather, cut[t], cut[t + 1], &errs[t]);
-            } catch (...) {  // no thread to be had: this one gathers that share too
-              gather(cut[t], cut[t + 1], &errs[t]);
-            }
-          }
-          if (cut[0] < cut[1]) gather(cut[0], cut[1], &errs[0]);
-          for (auto& t : th) t.join();
-          for (hipError_t x : errs)
-            if (x != hipSuccess && e == hipSuccess) e = x;
-        }
+        GatherPool::get().run(n_ranges, gather);
+        if (first_err.load() != (int)hipSuccess) e = (hipError_t)first_err.load();
         if (side) {  // the kernels follow every copy: the main stream takes the side stream's copies in
           hipError_t x = hipEventRecord(c->side_done, side);
           if (x == hipSuccess) x = hipStreamWaitEvent(c->stream, c->side_done, 0);
@@ -865,6 +953,7 @@ void ozcs_shutdown(void) {
     ctxs.swap(g.free_ctx);
   }
   for (HostCtx* c : ctxs) destroy_ctx(c);
+  GatherPool::get().stop();
   g.devs.clear();
   g.inited.store(false, std::memory_order_release);
 }
