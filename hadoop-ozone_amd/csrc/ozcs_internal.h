@@ -85,6 +85,8 @@ int fail_hip(hipError_t e, const char* what);
 HostCtx* acquire_ctx(int device);
 void release_ctx(HostCtx* c);
 int ctx_reserve(void** buf, size_t* cap, size_t need);
+// memcpy into pinned memory, shared with the gather pool's helper threads when large
+void pooled_copy(void* dst, const void* src, size_t n);
 
 int launch_windows(const DeviceInfo& dev, int type, uint32_t bpc, const void* d_data, uint64_t chunk_len,
                    uint64_t n_chunks, uint64_t chunk_stride, int mode, void* d_sums, const void* d_expected,

@@ -740,7 +740,7 @@ static int pipe_submit_impl(ozcs_pipe* p, int type, uint32_t bpc, const void* da
   void* buf = nullptr;
   int rc = pipe_acquire_impl(p, &buf, ticket);
   if (rc != OZCS_OK) return rc;
-  if (len) memcpy(buf, data, len);
+  if (len) pooled_copy(buf, data, len);
   return pipe_submit_slot_impl(p, *ticket, type, bpc, len, sums_out, sums_cap);
 }
 

@@ -36,15 +36,17 @@ def run_in_order(L, n_slots, n_chunks, mix, staged, bpc=MIB):
         while delivered < n_run:
             if submitted < n_run:
                 t = native.MD5 if (mix and not warm and submitted % 4 == 3) else native.CRC32
-                rc = L.ozcs_pipe_acquire_wait(pipe, ctypes.byref(buf), ctypes.byref(ticket))
+                if staged:                                # the library copies the chunk into a slot (shared with its helpers)
+                    rc = L.ozcs_pipe_submit(pipe, t, bpc, src.ctypes.data, 4 * MIB, outs[submitted % ring], cap, ctypes.byref(ticket))
+                else:
+                    rc = L.ozcs_pipe_acquire_wait(pipe, ctypes.byref(buf), ctypes.byref(ticket))
+                    if rc == native.OK:
+                        rc = L.ozcs_pipe_submit_slot(pipe, ticket.value, t, bpc, 4 * MIB, outs[submitted % ring], cap)
                 if rc == native.OK:
-                    if staged:
-                        ctypes.memmove(buf.value, src.ctypes.data, 4 * MIB)
-                    native.check(L.ozcs_pipe_submit_slot(pipe, ticket.value, t, bpc, 4 * MIB, outs[submitted % ring], cap))
                     submitted += 1
-                elif rc != native.EBUSY:                  # EBUSY: the backlog is full, deliver first
+                elif rc != native.EBUSY:                  # EBUSY: no slot free or the backlog is full, deliver first
                     native.check(rc)
-            block = 1 if submitted == n_run else 0
+            block = 1 if (submitted == n_run or rc == native.EBUSY) else 0
             while L.ozcs_pipe_next_in_order(pipe, block, ctypes.byref(done), None, None) == native.OK:
                 delivered += 1
                 block = 0
