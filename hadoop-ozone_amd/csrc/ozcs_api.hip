@@ -531,16 +531,18 @@ static int compute_host_on(int device, int type, uint32_t bpc, const void* data,
 // One device's share [lo, hi) of a chunk list, in groups of at most kBatchStageBytes of data.
 //
 // A copy call and a launch per chunk cost some 25 us per chunk whatever its size, and a copy from pageable
-// memory runs at half the link's rate.  So chunks of up to kStagedChunkBytes are gathered into one pinned
-// staging buffer, which is copied to the device in 8 MiB pieces while the gathering goes on; and the small
-// ones among them (at most kSmallChunkBytes and kSmallChunkWindows windows: small keys, the tail chunks of
-// files) get a descriptor per window (start, length, where the digest goes) and ONE launch per checksum type
-// works through the descriptors.  The others keep a launch of their own (a 4 MiB chunk occupies the memory
-// pipeline by itself); large SHA-256 / MD5 chunks go through the job-list kernel so that their few windows per
-// chunk add up to full wavefronts.  Digests come back in one copy when they fit the pinned return buffer.
+// memory runs at half the link's rate.  So chunks (of up to kStagedChunkBytes: larger ones arrive here cut into
+// pieces, except those of even larger windows, which take a copy of their own) are gathered into one pinned
+// staging buffer, range by range, each range copied to the device while the next are gathered (the caller's
+// thread and the gather pool's helpers share the ranges).  Launches follow the last copy, as few as the shapes
+// allow: CRC chunks of one shape that follow each other share one uniform launch; lone small chunks (at most
+// kSmallChunkBytes and kSmallChunkWindows windows: small keys, the tail chunks of files) get a descriptor per
+// window (start, length, where the digest goes) and ONE launch per checksum type works through the descriptors;
+// large SHA-256 / MD5 chunks go through the job-list kernel so that their few windows per chunk add up to full
+// wavefronts.  Digests come back in one copy when they fit the pinned return buffer.
 // Per-chunk status and n_sums are filled in.
 constexpr uint64_t kBatchStageBytes = 512ull << 20;  // also the most pinned memory one in-flight batch call holds
-constexpr uint64_t kStagedChunkBytes = 8ull << 20;
+constexpr uint64_t kStagedChunkBytes = 128ull << 20;  // larger chunks are hashed as pieces of whole windows of at most this
 constexpr uint64_t kSmallChunkBytes = 1ull << 20;
 constexpr uint64_t kSmallChunkWindows = 64;
 constexpr uint64_t kPinnedSumsMax = 32ull << 20;
@@ -851,13 +853,13 @@ static void batch_on_device(int device, ozcs_chunk* chunks, uint32_t lo, uint32_
   release_ctx(c);
 }
 
-// Appends one host buffer to a chunk list: as one chunk, or -- from kSplitCallBytes on -- as pieces of whole
-// windows, so that the batched path's pinned, threaded gather carries it instead of one copy from pageable
-// memory (40 GB/s and more against under 30).  `sums` receives the digests back to back either way.
+// Appends one host buffer to a chunk list: as one chunk, or -- from split_from bytes on -- as pieces of whole
+// windows of at most kStagedChunkBytes, so that the batched path's pinned, shared gather carries it instead of one
+// copy from pageable memory (over 50 GB/s against about 30).  `sums` receives the digests back to back either way.
 static void append_pieces(std::vector<ozcs_chunk>& out, int type, uint32_t bpc, const void* data, uint64_t len,
-                          void* sums, size_t ds) {
+                          void* sums, size_t ds, uint64_t split_from) {
   uint64_t piece = len, wpp = 0;
-  if (len >= kSplitCallBytes && bpc <= kStagedChunkBytes) {
+  if (len >= split_from && len > kStagedChunkBytes && bpc <= kStagedChunkBytes) {
     wpp = kStagedChunkBytes / bpc;
     piece = wpp * bpc;
   }
@@ -1096,7 +1098,7 @@ static int compute_impl(int type, uint32_t bpc, const void* data, uint64_t len, 
   s_calls.fetch_add(1, std::memory_order_relaxed);
   if (len >= kSplitCallBytes && bpc <= kStagedChunkBytes) {
     std::vector<ozcs_chunk> parts;
-    append_pieces(parts, type, bpc, data, len, sums_out, ds);
+    append_pieces(parts, type, bpc, data, len, sums_out, ds, kSplitCallBytes);
     batch_on_device(pick_device(), parts.data(), 0, (uint32_t)parts.size());
     for (const ozcs_chunk& p : parts)
       if (p.status != OZCS_OK) return p.status;
@@ -1195,6 +1197,53 @@ static int verify_impl(int type, uint32_t bpc, const void* data, uint64_t len, c
   return fail(OZCS_EHIP, "unexpected failure in %s", "ozcs_verify");
 }
 
+static int compute_batch_impl(ozcs_chunk* chunks, uint32_t n_chunks);
+
+// A chunk list with chunks too large to be staged whole (a copy from pageable memory carries 30 GB/s, the staged path
+// over 50): those are hashed as pieces of whole windows, each piece's digests going straight to its place in the
+// chunk's digest list, and the pieces' outcomes are folded back into the chunk.  Chunks the batched path will reject
+// (null pointers, a digest list too short) are handed on whole, so that it is the one place that judges them.
+static bool splittable(const ozcs_chunk& ch) {
+  if (ch.len <= kStagedChunkBytes || ch.bpc == 0 || ch.bpc > kStagedChunkBytes || !ch.data || !ch.sums) return false;
+  const size_t ds = ozcs_digest_size(ch.type);
+  return ds != 0 && ch.sums_cap >= ozcs_num_checksums(ch.len, ch.bpc) * ds;
+}
+
+static int compute_batch_split(ozcs_chunk* chunks, uint32_t n_chunks) {
+  std::vector<ozcs_chunk> parts;
+  std::vector<size_t> first(n_chunks + 1);
+  for (uint32_t i = 0; i < n_chunks; i++) {
+    first[i] = parts.size();
+    if (splittable(chunks[i]))
+      append_pieces(parts, chunks[i].type, chunks[i].bpc, chunks[i].data, chunks[i].len, chunks[i].sums,
+                    ozcs_digest_size(chunks[i].type), 0);
+    else
+      parts.push_back(chunks[i]);
+  }
+  first[n_chunks] = parts.size();
+  if (parts.size() > 0xffffffffull) return fail(OZCS_EINVAL, "chunk list too long once large chunks are cut into pieces");
+  const int inner = compute_batch_impl(parts.data(), (uint32_t)parts.size());
+  int rc = OZCS_OK;
+  for (uint32_t i = 0; i < n_chunks; i++) {
+    chunks[i].status = OZCS_OK;
+    chunks[i].n_sums = 0;
+    for (size_t k = first[i]; k < first[i + 1]; k++) {
+      if (parts[k].status != OZCS_OK) {
+        chunks[i].status = parts[k].status;
+        chunks[i].n_sums = 0;
+        break;
+      }
+      chunks[i].n_sums += parts[k].n_sums;
+    }
+    if (chunks[i].status != OZCS_OK && rc == OZCS_OK) rc = chunks[i].status;
+  }
+  if (inner != OZCS_OK && rc == OZCS_OK) {  // the call failed as a whole before any piece was judged
+    for (uint32_t i = 0; i < n_chunks; i++) { chunks[i].status = inner; chunks[i].n_sums = 0; }
+    rc = inner;
+  }
+  return rc;
+}
+
 static int compute_batch_impl(ozcs_chunk* chunks, uint32_t n_chunks) try {
   if (n_chunks == 0) return OZCS_OK;
   if (!chunks) return fail(OZCS_EINVAL, "null chunk list");
@@ -1203,6 +1252,8 @@ static int compute_batch_impl(ozcs_chunk* chunks, uint32_t n_chunks) try {
     for (uint32_t i = 0; i < n_chunks; i++) { chunks[i].status = rc; chunks[i].n_sums = 0; }
     return rc;
   }
+  for (uint32_t i = 0; i < n_chunks; i++)
+    if (splittable(chunks[i])) return compute_batch_split(chunks, n_chunks);
   Global& g = global();
   const size_t ndev = g.devs.size();
   s_calls.fetch_add(1, std::memory_order_relaxed);
@@ -1276,7 +1327,7 @@ static int verify_batch_impl(ozcs_vchunk* v, uint32_t n_chunks) try {
     const size_t ds = ozcs_digest_size(c.type);
     sums.emplace_back((size_t)(n * ds));
     const size_t first_job = jobs.size();
-    append_pieces(jobs, c.type, c.bpc, c.data, c.len, sums.back().data(), ds);
+    append_pieces(jobs, c.type, c.bpc, c.data, c.len, sums.back().data(), ds, 0);
     owners.push_back(Owner{i, first_job, jobs.size(), n});
   }
   if (!jobs.empty()) (void)compute_batch_impl(jobs.data(), (uint32_t)jobs.size());

@@ -57,6 +57,13 @@ constexpr uint32_t kEpochMask = (1u << 18) - 1;
 constexpr int kMaxDigestStreams = 8;
 constexpr int kMaxCopyStreams = 8;
 
+constexpr uint32_t kPastOutcomes = 16;
+struct Past {
+  uint32_t epoch = 0;
+  int status = OZCS_OK;
+  uint64_t n_sums = 0;
+};
+
 struct Slot {
   uint8_t* h_data = nullptr;  // pinned, slot_bytes
   uint8_t* d_data = nullptr;  // device, slot_bytes
@@ -74,12 +81,11 @@ struct Slot {
   void* user_sums = nullptr;
   uint64_t n_sums = 0, sums_len = 0;
   int status = OZCS_OK;
-  // outcome of the last tenancy that ended, for a holder that lost a race against ozcs_pipe_drain /
-  // ozcs_pipe_next_completed on another thread
-  uint32_t last_epoch = 0;
-  int last_status = OZCS_OK;
-  uint64_t last_n_sums = 0;
-  bool has_last = false;
+  // outcomes of the last tenancies that ended, for a holder that lost a race against ozcs_pipe_drain /
+  // ozcs_pipe_next_completed on another thread and asks for its ticket only later: the slot may have been let
+  // and retired again by then (kPastOutcomes - 1 times at most, or the ticket is unknown)
+  Past past[kPastOutcomes];
+  uint32_t n_past = 0;  // tenancies retired so far; entry i lives at past[i % kPastOutcomes]
   // threads inside ozcs_pipe_wait for a tenancy of this slot, waiting without the lock: the slot is not let
   // again before they have looked at the outcome, so the record above is always the one they need
   int waiters = 0;
@@ -180,10 +186,7 @@ hipError_t query_event(hipEvent_t ev) {
 // Ends a tenancy whose slot is kDone: hands the digests over and frees the slot.
 void retire(ozcs_pipe* p, Slot& s) {
   if (s.status == OZCS_OK && s.sums_len) memcpy(s.user_sums, s.h_sums, s.sums_len);
-  s.last_epoch = s.epoch;
-  s.last_status = s.status;
-  s.last_n_sums = s.n_sums;
-  s.has_last = true;
+  s.past[s.n_past++ % kPastOutcomes] = Past{s.epoch, s.status, s.n_sums};
   s.state = kFree;
   p->done_unclaimed--;
 }
@@ -398,21 +401,23 @@ void destroy_pipe(ozcs_pipe* p) {
   delete p;
 }
 
-// Resolves a ticket to its slot.  Returns OZCS_OK with *stale = false for the slot's current tenancy,
-// OZCS_OK with *stale = true when that tenancy has ended and its outcome is still on record, else OZCS_EINVAL.
-int resolve(ozcs_pipe* p, int ticket, Slot** out, bool* stale) {
+// Resolves a ticket to its slot.  Returns OZCS_OK with *stale = null for the slot's current tenancy,
+// OZCS_OK with *stale = the recorded outcome when that tenancy has ended and is still on record, else OZCS_EINVAL.
+int resolve(ozcs_pipe* p, int ticket, Slot** out, const Past** stale) {
   const int idx = ticket & kSlotMask;
   if (ticket < 0 || (size_t)idx >= p->slots.size()) return fail(OZCS_EINVAL, "bad ticket %d", ticket);
   Slot& s = p->slots[idx];
   const uint32_t epoch = ((uint32_t)ticket >> kSlotBits) & kEpochMask;
   *out = &s;
-  if (s.state != kFree && s.epoch == epoch) {
-    *stale = false;
-    return OZCS_OK;
-  }
-  if (s.has_last && s.last_epoch == epoch) {
-    *stale = true;
-    return OZCS_OK;
+  *stale = nullptr;
+  if (s.state != kFree && s.epoch == epoch) return OZCS_OK;
+  const uint32_t kept = s.n_past < kPastOutcomes ? s.n_past : kPastOutcomes;
+  for (uint32_t k = 1; k <= kept; k++) {  // newest first
+    const Past& q = s.past[(s.n_past - k) % kPastOutcomes];
+    if (q.epoch == epoch) {
+      *stale = &q;
+      return OZCS_OK;
+    }
   }
   return fail(OZCS_EINVAL, "ticket %d does not name a live slot tenancy", ticket);
 }
@@ -452,13 +457,13 @@ int finish(ozcs_pipe* p, int ticket, uint64_t* n_sums, bool block) {
   DeviceGuard dg(p->device);
   for (;;) {
     Slot* sp = nullptr;
-    bool stale = false;
+    const Past* stale = nullptr;
     const int rc = resolve(p, ticket, &sp, &stale);
     if (rc != OZCS_OK) return rc;
     Slot& s = *sp;
     if (stale) {  // completed by ozcs_pipe_drain / ozcs_pipe_next_completed on another thread
-      if (n_sums) *n_sums = s.last_n_sums;
-      return s.last_status;
+      if (n_sums) *n_sums = stale->n_sums;
+      return stale->status;
     }
     if (s.state == kAcquired) return fail(OZCS_EINVAL, "ticket %d was never submitted", ticket);
     reap(p);
@@ -481,7 +486,7 @@ int finish(ozcs_pipe* p, int ticket, uint64_t* n_sums, bool block) {
     s.waiters--;
     if (e != hipSuccess) {
       Slot* again = nullptr;
-      bool st = false;
+      const Past* st = nullptr;
       if (resolve(p, ticket, &again, &st) == OZCS_OK && !st && again->state == kInFlight) {
         mark_done(p, *again, fail_hip(e, "pipe completion"));
       }
@@ -611,7 +616,7 @@ static int pipe_release_impl(ozcs_pipe* p, int ticket) {
   if (!p) return fail(OZCS_EINVAL, "null pipe");
   std::lock_guard<std::mutex> lk(p->mu);
   Slot* sp = nullptr;
-  bool stale = false;
+  const Past* stale = nullptr;
   if (resolve(p, ticket, &sp, &stale) != OZCS_OK || stale || sp->state != kAcquired)
     return fail(OZCS_EINVAL, "ticket %d is not an acquired slot", ticket);
   sp->state = kFree;
@@ -665,7 +670,7 @@ static int pipe_submit_slot_impl(ozcs_pipe* p, int ticket, int type, uint32_t bp
   if (!p) return fail(OZCS_EINVAL, "null pipe");
   std::lock_guard<std::mutex> lk(p->mu);
   Slot* sp = nullptr;
-  bool stale = false;
+  const Past* stale = nullptr;
   if (resolve(p, ticket, &sp, &stale) != OZCS_OK || stale || sp->state != kAcquired)
     return fail(OZCS_EINVAL, "ticket %d is not an acquired slot", ticket);
   Slot& s = *sp;

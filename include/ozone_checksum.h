@@ -249,7 +249,9 @@ OZCS_API int ozcs_pipe_wait(ozcs_pipe* pipe, int ticket, uint64_t* n_sums);
  * outstanding.  status and n_sums may be NULL. */
 OZCS_API int ozcs_pipe_next_completed(ozcs_pipe* pipe, int block, int* ticket, int* status, uint64_t* n_sums);
 /* Blocks until every submitted ticket has completed (their slots are freed).  Returns the first failure among
- * them, or OZCS_OK. */
+ * them, or OZCS_OK.  A thread that holds one of those tickets may still poll or wait for it afterwards (its digests
+ * are already in its sums_out): the pipe remembers the outcomes of a slot's last 16 tenancies, older tickets are
+ * answered with OZCS_EINVAL. */
 OZCS_API int ozcs_pipe_drain(ozcs_pipe* pipe);
 
 /* ---- in-order delivery: the write path of BlockOutputStream ships chunk n before chunk n+1 ----

@@ -11,13 +11,14 @@ MIB = 1 << 20
 L = native.lib()
 native.check(L.ozcs_init(0))
 rng = np.random.default_rng(0)
-for n, size in ((16, 4 * MIB), (64, 4 * MIB), (128, 4 * MIB), (256, MIB), (32, 8 * MIB), (1024, 256 * 1024)):
+for n, size in ((16, 4 * MIB), (64, 4 * MIB), (128, 4 * MIB), (256, MIB), (32, 8 * MIB), (1024, 256 * 1024), (16, 32 * MIB), (6, 80 * MIB)):
     bufs = [rng.integers(0, 256, size, dtype=np.uint8) for _ in range(n)]
     arr = (native.OzcsChunk * n)()
-    outs = [ctypes.create_string_buffer(64) for _ in range(n)]
+    cap = max(64, (size // MIB + 1) * 4)
+    outs = [ctypes.create_string_buffer(cap) for _ in range(n)]
     for i in range(n):
         arr[i].data, arr[i].len = bufs[i].ctypes.data, size
-        arr[i].sums, arr[i].sums_cap = ctypes.cast(outs[i], ctypes.c_void_p).value, 64
+        arr[i].sums, arr[i].sums_cap = ctypes.cast(outs[i], ctypes.c_void_p).value, cap
         arr[i].bpc, arr[i].type = MIB, native.CRC32
     native.check(L.ozcs_compute_batch(arr, n))
     reps = max(4, (4096 * MIB) // (n * size))

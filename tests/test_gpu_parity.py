@@ -774,6 +774,48 @@ def test_compute_batch_runs_of_equal_chunks(gpu):
     assert after["kernel_launches"] - before["kernel_launches"] == 14 + 3
 
 
+def test_compute_batch_chunks_larger_than_the_staging_piece(gpu):
+    """Chunks of more than 128 MiB inside a batch are hashed as pieces of whole windows: lengths that are no multiple
+    of the piece or of the window, a window size that does not divide the piece, a digest type, large chunks that are
+    staged whole beside them, and a rejected chunk (digest list too short) among them, which must fail alone."""
+    torch, native, L = gpu
+    C, CC, S, M = oracle.CRC32, oracle.CRC32C, oracle.SHA256, oracle.MD5
+    plan = [(C, MIB, 130 * MIB), (CC, 16384, 129 * MIB + 12345), (C, 3 * MIB + 1, 140 * MIB), (M, 65536, 128 * MIB + 1),
+            (S, MIB, 9 * MIB), (C, MIB, 4 * MIB), (CC, 12 * MIB, 30 * MIB), (C, 100000, 8 * MIB + 1), (C, 512, 17 * MIB)]
+    n = len(plan)
+    arr = (native.OzcsChunk * (n + 1))()
+    bufs, outs = [], []
+    for i, (t, bpc, ln) in enumerate(plan):
+        b = oracle.splitmix64(9300 + i, ln)
+        o = ctypes.create_string_buffer(((ln + bpc - 1) // bpc) * native.DIGEST_SIZE[t])
+        bufs.append(b)
+        outs.append(o)
+        arr[i].data, arr[i].len = b.ctypes.data, ln
+        arr[i].sums, arr[i].sums_cap = ctypes.cast(o, ctypes.c_void_p).value, len(o)
+        arr[i].bpc, arr[i].type = bpc, t
+    # the rejected one: 16 MiB at 1 MiB windows needs 64 bytes of digests, 60 are offered
+    short = ctypes.create_string_buffer(b"\xEE" * 60, 60)
+    arr[n].data, arr[n].len = bufs[0].ctypes.data, 16 * MIB
+    arr[n].sums, arr[n].sums_cap = ctypes.cast(short, ctypes.c_void_p).value, 60
+    arr[n].bpc, arr[n].type = MIB, C
+    assert L.ozcs_compute_batch(arr, n + 1) == native.EINVAL
+    assert arr[n].status == native.EINVAL and arr[n].n_sums == 0 and short.raw == b"\xEE" * 60
+    for i, (t, bpc, ln) in enumerate(plan):
+        assert arr[i].status == native.OK and arr[i].n_sums == (ln + bpc - 1) // bpc, (i, t, bpc, ln)
+        assert outs[i].raw == oracle.compute(t, bpc, bufs[i]), (i, t, bpc, ln)
+    # the same list through ozcs_verify_batch: stored digests of chunk 1 get one flipped bit in window 300
+    v = (native.OzcsVChunk * n)()
+    stored = [bytearray(o.raw) for o in outs]
+    stored[1][300 * 4] ^= 1
+    keep = [(ctypes.c_char * len(x)).from_buffer(x) for x in stored]
+    for i, (t, bpc, ln) in enumerate(plan):
+        v[i].data, v[i].len = bufs[i].ctypes.data, ln
+        v[i].expected, v[i].n_expected = ctypes.addressof(keep[i]), (ln + bpc - 1) // bpc
+        v[i].start_index, v[i].bpc, v[i].type = 0, bpc, t
+    assert L.ozcs_verify_batch(v, n) == native.OK
+    assert [v[i].first_mismatch for i in range(n)] == [-1, 300] + [-1] * (n - 2)
+
+
 def test_full_size_properties_other_configurations(gpu):
     """The per-GPU share of the 16 KiB verify configuration (8 GiB, 524,288 windows) and the whole SHA-256
     configuration (32 GiB at 1 MiB windows, 32,768 windows): sampled windows against the oracle, permutation

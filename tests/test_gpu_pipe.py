@@ -191,12 +191,42 @@ def test_pipe_ticket_names_one_tenancy(gpu):
         assert n.value == 16
         native.check(L.ozcs_pipe_wait(pipe, t2.value, ctypes.byref(n)))
         assert n.value == 1 and out2.raw == oracle.compute(oracle.MD5, MIB, d)
-        assert L.ozcs_pipe_poll(pipe, t1.value, None) == native.EINVAL   # only the last ended tenancy is on record
+        native.check(L.ozcs_pipe_poll(pipe, t1.value, ctypes.byref(n)))   # tenancy 1 is still on record behind tenancy 2
+        assert n.value == 16
         assert L.ozcs_pipe_poll(pipe, 12345678, None) == native.EINVAL
         assert L.ozcs_pipe_poll(pipe, -1, None) == native.EINVAL
         assert L.ozcs_pipe_ticket_slot(-5) == -1
     finally:
         L.ozcs_pipe_destroy(pipe)
+
+
+def test_pipe_ticket_answered_after_its_slot_was_drained_and_let_again(gpu):
+    # a holder that comes for its ticket late: the slot was freed by ozcs_pipe_drain and has had other tenancies since.
+    # The pipe remembers a slot's last 16 outcomes; the digests were delivered when the slot was drained.
+    torch, native, L = gpu
+    pipe = ctypes.c_void_p()
+    native.check(L.ozcs_pipe_create(0, 1, 2 * MIB, ctypes.byref(pipe)))     # one slot: every submission is a new tenancy of it
+    tickets, outs, datas = [], [], []
+    n = ctypes.c_uint64()
+    for i in range(18):
+        ln = 65536 * (i + 1)
+        d = oracle.splitmix64(610 + i, ln)
+        out = ctypes.create_string_buffer(4 * (i + 1))
+        t = ctypes.c_int(-1)
+        native.check(L.ozcs_pipe_submit(pipe, oracle.CRC32C, 65536, d.ctypes.data, ln, out, len(out), ctypes.byref(t)))
+        native.check(L.ozcs_pipe_drain(pipe))
+        assert out.raw == oracle.compute(oracle.CRC32C, 65536, d)
+        tickets.append(t.value)
+        outs.append(out)
+        datas.append(d)
+    assert len(set(tickets)) == 18
+    for i in range(2, 18):                                               # the last 16 tenancies are on record
+        n.value = 0
+        assert L.ozcs_pipe_wait(pipe, tickets[i], ctypes.byref(n)) == native.OK and n.value == i + 1
+        assert L.ozcs_pipe_poll(pipe, tickets[i], ctypes.byref(n)) == native.OK and n.value == i + 1
+    for i in range(2):                                                   # older ones are not
+        assert L.ozcs_pipe_wait(pipe, tickets[i], ctypes.byref(n)) == native.EINVAL
+    L.ozcs_pipe_destroy(pipe)
 
 
 def test_pipe_waiters_against_concurrent_drain(gpu):
