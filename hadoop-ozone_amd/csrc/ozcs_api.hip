@@ -322,6 +322,7 @@ constexpr uint64_t kStagePiece = 8ull << 20;            // largest byte range of
 constexpr size_t kGatherThreads = 4;                    // the caller and three helpers
 constexpr uint64_t kGatherRangeMin = 256ull << 10;      // smallest byte range one gather part copies and sends
 constexpr uint64_t kGatherNtMinBytes = 8ull << 20;      // staged data from which the gather writes around the cache
+constexpr uint64_t kLonePinnedSumsMax = 1ull << 20;     // a lone call's digests return through pinned memory up to this size
 
 // ---- helper threads of the gathers (host copies of caller memory into pinned staging) ----
 // A caller publishes a job of n parts and works through the parts itself; helpers that are awake claim parts beside
@@ -498,8 +499,12 @@ static int compute_host_on(int device, int type, uint32_t bpc, const void* data,
   if (!dg.ok()) return fail(OZCS_ENODEV, "cannot select device %d", device);
   HostCtx* c = acquire_ctx(device);
   if (!c) return fail(OZCS_EHIP, "cannot create a stream on device %d", device);
+  // digests come back through pinned memory when they are few: a copy into the caller's pageable buffer goes through the
+  // runtime's own staging and a wait inside the call
+  const bool pinned_sums = n * ds <= kLonePinnedSumsMax;
   int rc = ctx_reserve(&c->d_data, &c->data_cap, len);
   if (rc == OZCS_OK) rc = ctx_reserve(&c->d_sums, &c->sums_cap, n * ds);
+  if (rc == OZCS_OK && pinned_sums) rc = host_reserve(&c->h_sums, &c->h_sums_cap, n * ds);
   hipError_t e = hipSuccess;
   PhaseTimer timer(c, len);
   timer.mark(0);
@@ -513,13 +518,14 @@ static int compute_host_on(int device, int type, uint32_t bpc, const void* data,
                         c->stream);
   timer.mark(2);
   if (rc == OZCS_OK) {
-    e = hipMemcpyAsync(sums_out, c->d_sums, n * ds, hipMemcpyDeviceToHost, c->stream);
+    e = hipMemcpyAsync(pinned_sums ? c->h_sums : sums_out, c->d_sums, n * ds, hipMemcpyDeviceToHost, c->stream);
     if (e != hipSuccess) rc = fail_hip(e, "hipMemcpyAsync D2H");
   }
   timer.mark(3);
   e = hipStreamSynchronize(c->stream);
   if (rc == OZCS_OK && e != hipSuccess) rc = fail_hip(e, "hipStreamSynchronize");
   if (rc == OZCS_OK) {
+    if (pinned_sums) memcpy(sums_out, c->h_sums, n * ds);
     timer.finish();
     s_h2d.fetch_add(len, std::memory_order_relaxed);
     s_d2h.fetch_add(n * ds, std::memory_order_relaxed);
@@ -1154,6 +1160,7 @@ static int verify_impl(int type, uint32_t bpc, const void* data, uint64_t len, c
   rc = ctx_reserve(&c->d_data, &c->data_cap, len);
   if (rc == OZCS_OK) rc = ctx_reserve(&c->d_sums, &c->sums_cap, (ship ? ship : 1) * ds);
   if (rc == OZCS_OK) rc = ctx_reserve(&c->d_aux, &c->aux_cap, sizeof(int64_t));
+  if (rc == OZCS_OK) rc = host_reserve(&c->h_sums, &c->h_sums_cap, sizeof(int64_t));
   hipError_t e = hipSuccess;
   int64_t fm = -1;
   PhaseTimer timer(c, len);
@@ -1171,14 +1178,17 @@ static int verify_impl(int type, uint32_t bpc, const void* data, uint64_t len, c
     rc = launch_windows(*dev, type, bpc, c->d_data, len, 1, len, kModeVerify, nullptr, c->d_sums, 0, ship, 0,
                         static_cast<unsigned long long*>(c->d_aux), c->stream);
   timer.mark(2);
-  if (rc == OZCS_OK) {
-    e = hipMemcpyAsync(&fm, c->d_aux, sizeof fm, hipMemcpyDeviceToHost, c->stream);
+  if (rc == OZCS_OK) {  // the verdict word returns through pinned memory, as a lone compute call's digests do
+    e = hipMemcpyAsync(c->h_sums, c->d_aux, sizeof fm, hipMemcpyDeviceToHost, c->stream);
     if (e != hipSuccess) rc = fail_hip(e, "hipMemcpyAsync D2H");
   }
   timer.mark(3);
   e = hipStreamSynchronize(c->stream);
   if (rc == OZCS_OK && e != hipSuccess) rc = fail_hip(e, "hipStreamSynchronize");
-  if (rc == OZCS_OK) timer.finish();
+  if (rc == OZCS_OK) {
+    memcpy(&fm, c->h_sums, sizeof fm);
+    timer.finish();
+  }
   release_ctx(c);
   if (rc != OZCS_OK) return rc;
   s_h2d.fetch_add(len + ship * ds, std::memory_order_relaxed);
