@@ -3,7 +3,7 @@
 blocks (4 MiB chunks), the `Checksum.computeChecksum` work of BlockOutputStream.writeChunkToContainer
 (BlockOutputStream.java:645-656) for every chunk of the batch, in one launch per step.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 20 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -217,7 +217,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--blocks", type=int, default=64, help="256 MiB blocks resident per GPU (64 = 16 GiB)")
     ap.add_argument("--type", default="CRC32", choices=["CRC32", "CRC32C", "SHA256", "MD5"])
     ap.add_argument("--bpc", type=int, default=MIB)

@@ -6,5 +6,5 @@ run
 run --type CRC32C --bpc 16384 --mode verify
 run --type SHA256 --blocks 128 --steps 3 --warmup 1
 run --type MD5 --blocks 128 --steps 3 --warmup 1
-run --type SHA256 --bpc 16384 --blocks 32 --steps 3 --warmup 1 --no-cpu-baseline
-run --type MD5 --bpc 16384 --blocks 32 --steps 3 --warmup 1 --no-cpu-baseline
+run --type SHA256 --bpc 16384 --blocks 32 --steps 20 --warmup 10 --no-cpu-baseline
+run --type MD5 --bpc 16384 --blocks 32 --steps 20 --warmup 10 --no-cpu-baseline
