@@ -147,6 +147,88 @@ __global__ __launch_bounds__(1024) void read_flat_pattern(const uint8_t* p, uint
   if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = lds[0];
 }
 
+// The flat pattern with a rolling queue of D stripe groups per wavefront (requests cross from one window group into the
+// next, explicit loads and vmcnt waits) and, optionally, the CRC kernels' kind of work between the requests:
+// WORK & 1: sixteen conflict-free LDS lookups per 16-byte unit (lane l reads bank l % 32 of a random row),
+// WORK & 2: twenty-four dependent vector instructions per unit.  Shows what the memory system delivers to this request
+// stream when the CUs are idle, busy in the LDS, busy in the vector ALUs, or both.
+__device__ __forceinline__ void ld_async(u32x4& v, const uint8_t* a) {
+  asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(v) : "v"(a) : "memory");
+}
+template <int K>
+__device__ __forceinline__ void wait_vm(u32x4& a, u32x4& b) {
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(K) : "memory");
+}
+template <int WORK>
+__device__ __forceinline__ void unit_work(const char* lds, uint32_t lane4, u32x4& acc, const u32x4 d) {
+  if (WORK & 1) {
+    uint32_t r[4] = {acc.x, acc.y, acc.z, acc.w};
+    const uint32_t dd[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      uint32_t t = dd[q];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t row = (r[q] >> (8 * k)) & 0xffu;
+        t ^= *reinterpret_cast<const uint32_t*>(lds + row * 128u + lane4 + k * 32768u);
+      }
+      r[q] = t;
+    }
+    acc.x = r[0]; acc.y = r[1]; acc.z = r[2]; acc.w = r[3];
+  }
+  if (WORK & 2) {
+    uint32_t r[4] = {acc.x, acc.y, acc.z, acc.w};
+    const uint32_t dd[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) r[q] = __builtin_amdgcn_perm(r[q], dd[q], 0x05020704u + k) ^ (r[q] >> (k + 1));
+    }
+    acc.x = r[0]; acc.y = r[1]; acc.z = r[2]; acc.w = r[3];
+  }
+  if (WORK == 0) acc ^= d;
+}
+template <int LPW, int NST, int D, int WORK>
+__global__ __launch_bounds__(1024) void read_flat_rolling(const uint8_t* p, uint64_t nwin, uint32_t* out) {
+  __shared__ char lds[157696];
+  for (int i = threadIdx.x; i < 131072 / 4; i += 1024) reinterpret_cast<uint32_t*>(lds)[i] = i * 2654435761u;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  constexpr int kPerRow = 64 / LPW;
+  constexpr uint32_t kStripe = 16u * LPW, kWin = kStripe * NST;
+  const int sl = lane & (LPW - 1), grp = lane / LPW;
+  const uint32_t lane4 = (lane & 31) * 4u;
+  const uint64_t step = (uint64_t)gridDim.x * 16 * 2 * kPerRow;
+  uint64_t w0 = ((uint64_t)blockIdx.x * 16 + wave) * 2 * kPerRow;
+  auto row = [&](uint64_t w, int r) { uint64_t g = w + r * kPerRow + grp; if (g >= nwin) g = nwin - 1; return p + g * kWin + 16 * sl; };
+  const uint8_t *wa = row(w0, 0), *wb = row(w0, 1);
+  u32x4 qa[NST], qb[NST];
+#pragma unroll
+  for (int k = 0; k < D; k++) { ld_async(qa[k], wa + k * kStripe); ld_async(qb[k], wb + k * kStripe); }
+  u32x4 acc = {0, 0, 0, 0}, acc2 = {1, 2, 3, 4};
+  for (; w0 < nwin; w0 += step) {
+    const uint8_t *na = row(w0 + step, 0), *nb = row(w0 + step, 1);  // past the end: the last window again
+#pragma unroll
+    for (int s = 0; s < NST; s++) {
+      const int t = s + D;
+      if (D < NST) {
+        if (t < NST) { ld_async(qa[t], wa + t * kStripe); ld_async(qb[t], wb + t * kStripe); }
+        else { ld_async(qa[t - NST], na + (t - NST) * kStripe); ld_async(qb[t - NST], nb + (t - NST) * kStripe); }
+        wait_vm<2 * D>(qa[s], qb[s]);
+      } else {
+        wait_vm<2 * (NST - 1)>(qa[s], qb[s]);
+      }
+      unit_work<WORK>(lds, lane4, acc, qa[s]);
+      unit_work<WORK>(lds, lane4, acc2, qb[s]);
+      if (D == NST) { ld_async(qa[s], na + s * kStripe); ld_async(qb[s], nb + s * kStripe); }
+    }
+    wa = na; wb = nb;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  acc ^= acc2;
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = lds[5];
+}
+
 // the same with ROWS 1 KiB rows per wavefront and stripe, and PF stripes ahead
 template <int G, int ROWS, int PF>
 __global__ __launch_bounds__(1024) void read_crc_rows(const uint8_t* p, uint64_t nwin, uint64_t win, uint32_t* out) {
@@ -231,6 +313,16 @@ int main(int argc, char** argv) {
     timeit("crc pattern G=2 (prefetch 1, nt)", bytes, [&] { read_crc_pattern<2><<<256, 1024>>>(d, nwin, win, out); });
     timeit("crc pattern G=4 (prefetch 1, nt)", bytes, [&] { read_crc_pattern<4><<<256, 1024>>>(d, nwin, win, out); });
     timeit("crc pattern G=8 (prefetch 1, nt)", bytes, [&] { read_crc_pattern<8><<<256, 1024>>>(d, nwin, win, out); });
+    return 0;
+  }
+  if (argc > 2 && !strcmp(argv[2], "rolling")) {   // request depth x kind of work between the requests, 512-byte windows, 8 lanes
+    const uint64_t nw = bytes / 512;
+#define ROLL(D, W, label) timeit("512 B windows, 8 lanes, " #D " stripe groups in flight, " label, bytes, [&] { read_flat_rolling<8, 4, D, W><<<256, 1024>>>(d, nw, out); });
+    ROLL(1, 0, "no work") ROLL(2, 0, "no work") ROLL(4, 0, "no work")
+    ROLL(1, 1, "LDS lookups") ROLL(2, 1, "LDS lookups") ROLL(4, 1, "LDS lookups")
+    ROLL(1, 2, "vector ALU") ROLL(2, 2, "vector ALU") ROLL(4, 2, "vector ALU")
+    ROLL(1, 3, "LDS lookups + vector ALU") ROLL(2, 3, "LDS lookups + vector ALU") ROLL(4, 3, "LDS lookups + vector ALU")
+#undef ROLL
     return 0;
   }
   if (argc > 2 && !strcmp(argv[2], "flat")) {   // bare reads in the small-window kernels' pattern, window size x lanes per window
