@@ -9,14 +9,11 @@ export ROUND=$R
 # Launches of a few milliseconds are preceded by ten untimed ones: after an idle second the chip runs the first launches of a
 # sequence well below the clock it then holds (MD5 at 16 KiB windows: 4.1 TB/s over launches 2-4, 5.4 over launches 11-30).
 # rocprofv3 passes first, and their summary: every bench line after them carries the measured traffic of these very sources
-TAG=headline bash scripts/profile_config.sh --steps 30 --warmup 10 > $O/prof_headline.log 2>&1 || exit 1
-TAG=cfg3 bash scripts/profile_config.sh --type CRC32C --bpc 16384 --mode verify --steps 20 --warmup 10 > $O/prof_cfg3.log 2>&1 || exit 1
-TAG=cfg4 bash scripts/profile_config.sh --type SHA256 --blocks 128 --steps 3 --warmup 1 > $O/prof_cfg4.log 2>&1 || exit 1
-TAG=sha16k bash scripts/profile_config.sh --type SHA256 --bpc 16384 --blocks 32 --steps 20 --warmup 10 > $O/prof_sha16k.log 2>&1 || exit 1
-TAG=md516k bash scripts/profile_config.sh --type MD5 --bpc 16384 --blocks 32 --steps 20 --warmup 10 > $O/prof_md516k.log 2>&1 || exit 1
-TAG=flat512 bash scripts/profile_config.sh --type CRC32 --bpc 512 --steps 20 --warmup 10 > $O/prof_flat512.log 2>&1 || exit 1
-TAG=flat16k bash scripts/profile_config.sh --type CRC32 --bpc 16384 --steps 20 --warmup 10 > $O/prof_flat16k.log 2>&1 || exit 1
-bash scripts/collect_round.sh > $O/collect.log 2>&1 || exit 1
+# (SKIP_PROFILES=1: the passes ran in an earlier call and profiles/pmc_summary.json already holds their summary)
+if [ "${SKIP_PROFILES:-0}" != 1 ]; then
+  bash scripts/final_profiles.sh > $O/final_profiles.log 2>&1 || exit 1
+  bash scripts/collect_round.sh > $O/collect.log 2>&1 || exit 1
+fi
 bash scripts/run_configs.sh > $O/${R}_configs.log 2>&1 || exit 1
 bash scripts/crc_configs.sh > $O/${R}_crc_window_sizes.log 2>&1 || exit 1
 timeout -k 10 400 python -u scripts/bench_pipeline.py 2>/dev/null > $O/${R}_pipeline_end_to_end.log || exit 1

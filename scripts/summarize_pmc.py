@@ -43,7 +43,7 @@ def kernel_times():
     for f in glob.glob(os.path.join(OUT, "prof_%s_trace" % TAG, "**", "*kernel_stats.csv"), recursive=True):
         shutil.copy(f, os.path.join(ROOT, "profiles", "%s_kernel_stats_%s.csv" % (os.environ.get("ROUND", "r03"), TAG)))
         for r in csv.DictReader(open(f)):
-            if KERNEL in r["Name"]:
+            if KERNEL in r["Name"] and int(r["Calls"]) > calls:   # the variant the run is about: the one launched most
                 avg_ns, calls = float(r["AverageNs"]), int(r["Calls"])
     for f in glob.glob(os.path.join(OUT, "prof_%s_trace" % TAG, "**", "*kernel_trace.csv"), recursive=True):
         rows = [r for r in csv.DictReader(open(f)) if KERNEL in r["Kernel_Name"]]

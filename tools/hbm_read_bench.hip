@@ -189,7 +189,7 @@ __device__ __forceinline__ void unit_work(const char* lds, uint32_t lane4, u32x4
   if (WORK == 0) acc ^= d;
 }
 template <int LPW, int NST, int D, int WORK>
-__global__ __launch_bounds__(1024) void read_flat_rolling(const uint8_t* p, uint64_t nwin, uint32_t* out) {
+__global__ __launch_bounds__(1024) void read_flat_rolling(const uint8_t* p, uint64_t nwin, uint32_t* out, uint32_t* digests) {
   __shared__ char lds[157696];
   for (int i = threadIdx.x; i < 131072 / 4; i += 1024) reinterpret_cast<uint32_t*>(lds)[i] = i * 2654435761u;
   __syncthreads();
@@ -221,6 +221,46 @@ __global__ __launch_bounds__(1024) void read_flat_rolling(const uint8_t* p, uint
       unit_work<WORK>(lds, lane4, acc, qa[s]);
       unit_work<WORK>(lds, lane4, acc2, qb[s]);
       if (D == NST) { ld_async(qa[s], na + s * kStripe); ld_async(qb[s], nb + s * kStripe); }
+    }
+    if (WORK & 8) {  // a per-window fold's shape: seven LDS round trips in a row, each waiting for the one before
+#pragma unroll
+      for (int k = 0; k < 7; k++) {
+        uint32_t t0 = 0, t1 = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          t0 ^= *reinterpret_cast<const uint32_t*>(lds + ((acc.x >> (8 * q)) & 0xffu) * 128u + lane4 + q * 32768u);
+          t1 ^= *reinterpret_cast<const uint32_t*>(lds + ((acc2.x >> (8 * q)) & 0xffu) * 128u + lane4 + q * 32768u);
+        }
+        acc.x = t0 ^ acc.y;
+        acc2.x = t1 ^ acc2.y;
+      }
+    }
+    if ((WORK & 4) && sl == LPW - 1) {  // the digests of the window group: two 32-byte pieces per wavefront
+      if (WORK & 16) {  // into a region small enough to stay in the L2: the store instructions without the DRAM writes
+        digests[(w0 + grp) & 0xffff] = acc.x;
+        digests[(w0 + kPerRow + grp) & 0xffff] = acc2.x;
+      } else if (WORK & 32) {  // non-temporal stores
+        __builtin_nontemporal_store(acc.x, digests + w0 + grp);
+        __builtin_nontemporal_store(acc2.x, digests + w0 + kPerRow + grp);
+      } else if (WORK & 128) {  // write-through stores (system scope)
+        asm volatile("global_store_dword %0, %1, off sc0 sc1" : : "v"(digests + w0 + grp), "v"(acc.x) : "memory");
+        asm volatile("global_store_dword %0, %1, off sc0 sc1" : : "v"(digests + w0 + kPerRow + grp), "v"(acc2.x) : "memory");
+      } else if (WORK & 256) {  // write-through, streaming
+        asm volatile("global_store_dword %0, %1, off sc0 sc1 nt" : : "v"(digests + w0 + grp), "v"(acc.x) : "memory");
+        asm volatile("global_store_dword %0, %1, off sc0 sc1 nt" : : "v"(digests + w0 + kPerRow + grp), "v"(acc2.x) : "memory");
+      } else if (WORK & 512) {  // device scope
+        asm volatile("global_store_dword %0, %1, off sc1" : : "v"(digests + w0 + grp), "v"(acc.x) : "memory");
+        asm volatile("global_store_dword %0, %1, off sc1" : : "v"(digests + w0 + kPerRow + grp), "v"(acc2.x) : "memory");
+      } else if (WORK & 64) {  // every fourth window group, four times the bytes: fewer store instructions, whole lines
+        if (((w0 / step) & 3) == 3) {
+          const u32x4 va = {acc.x, acc.y, acc.z, acc.w}, vb = {acc2.x, acc2.y, acc2.z, acc2.w};
+          *reinterpret_cast<u32x4*>(digests + ((w0 / step) >> 2) * 4 * 16 * ((uint64_t)gridDim.x * 16) + ((uint64_t)blockIdx.x * 16 + wave) * 64 + grp * 4) = va;
+          *reinterpret_cast<u32x4*>(digests + ((w0 / step) >> 2) * 4 * 16 * ((uint64_t)gridDim.x * 16) + ((uint64_t)blockIdx.x * 16 + wave) * 64 + 32 + grp * 4) = vb;
+        }
+      } else {
+        digests[w0 + grp] = acc.x;
+        digests[w0 + kPerRow + grp] = acc2.x;
+      }
     }
     wa = na; wb = nb;
   }
@@ -317,11 +357,21 @@ int main(int argc, char** argv) {
   }
   if (argc > 2 && !strcmp(argv[2], "rolling")) {   // request depth x kind of work between the requests, 512-byte windows, 8 lanes
     const uint64_t nw = bytes / 512;
-#define ROLL(D, W, label) timeit("512 B windows, 8 lanes, " #D " stripe groups in flight, " label, bytes, [&] { read_flat_rolling<8, 4, D, W><<<256, 1024>>>(d, nw, out); });
+    uint32_t* dig;
+    CK(hipMalloc(&dig, nw * 4));
+#define ROLL(D, W, label) timeit("512 B windows, 8 lanes, " #D " stripe groups in flight, " label, bytes, [&] { read_flat_rolling<8, 4, D, W><<<256, 1024>>>(d, nw, out, dig); });
     ROLL(1, 0, "no work") ROLL(2, 0, "no work") ROLL(4, 0, "no work")
     ROLL(1, 1, "LDS lookups") ROLL(2, 1, "LDS lookups") ROLL(4, 1, "LDS lookups")
     ROLL(1, 2, "vector ALU") ROLL(2, 2, "vector ALU") ROLL(4, 2, "vector ALU")
     ROLL(1, 3, "LDS lookups + vector ALU") ROLL(2, 3, "LDS lookups + vector ALU") ROLL(4, 3, "LDS lookups + vector ALU")
+    ROLL(1, 5, "LDS lookups + digest stores") ROLL(2, 5, "LDS lookups + digest stores") ROLL(4, 5, "LDS lookups + digest stores")
+    ROLL(1, 21, "LDS lookups + digest stores that stay in the L2") ROLL(4, 21, "LDS lookups + digest stores that stay in the L2")
+    ROLL(1, 37, "LDS lookups + non-temporal digest stores") ROLL(4, 37, "LDS lookups + non-temporal digest stores")
+    ROLL(1, 133, "LDS lookups + digest stores sc0 sc1") ROLL(1, 261, "LDS lookups + digest stores sc0 sc1 nt") ROLL(1, 517, "LDS lookups + digest stores sc1")
+    ROLL(1, 69, "LDS lookups + digest stores every fourth group, whole lines") ROLL(4, 69, "LDS lookups + digest stores every fourth group, whole lines")
+    ROLL(1, 9, "LDS lookups + serial fold") ROLL(2, 9, "LDS lookups + serial fold") ROLL(4, 9, "LDS lookups + serial fold")
+    ROLL(1, 13, "LDS lookups + serial fold + digest stores") ROLL(2, 13, "LDS lookups + serial fold + digest stores")
+    ROLL(4, 13, "LDS lookups + serial fold + digest stores")
 #undef ROLL
     return 0;
   }
