@@ -152,8 +152,11 @@ __global__ __launch_bounds__(1024) void read_flat_pattern(const uint8_t* p, uint
 // WORK & 1: sixteen conflict-free LDS lookups per 16-byte unit (lane l reads bank l % 32 of a random row),
 // WORK & 2: twenty-four dependent vector instructions per unit.  Shows what the memory system delivers to this request
 // stream when the CUs are idle, busy in the LDS, busy in the vector ALUs, or both.
+#ifndef ROLLING_LOAD_POLICY
+#define ROLLING_LOAD_POLICY "nt"
+#endif
 __device__ __forceinline__ void ld_async(u32x4& v, const uint8_t* a) {
-  asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(v) : "v"(a) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, off " ROLLING_LOAD_POLICY : "=v"(v) : "v"(a) : "memory");
 }
 template <int K>
 __device__ __forceinline__ void wait_vm(u32x4& a, u32x4& b) {
