@@ -82,13 +82,34 @@ __global__ __launch_bounds__(1024) void read_wave_windows_policy(const uint8_t* 
 
 // exactly the CRC kernel's pattern: G wavefronts share a window, stripe = 2*G KiB, each wavefront reads two 1 KiB
 // rows of every stripe, one stripe prefetched ahead (non-temporal loads)
-template <int G>
+// XCDMAP: workgroups go to the chip's eight XCDs round robin (workgroup b runs on XCD b % 8).  0: workgroup b takes the b-th
+// share of every pass over the windows, so the eight XCDs' shares interleave; 1: XCD x takes the x-th eighth of every
+// pass (its workgroups' shares lie side by side); 2: XCD x takes the x-th eighth of the whole batch.
+template <int G, int XCDMAP = 0>
 __global__ __launch_bounds__(1024) void read_crc_pattern(const uint8_t* p, uint64_t nwin, uint64_t win, uint32_t* out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = wave / G, wsub = wave % G;
   constexpr uint64_t kStripe = 2048ull * G;
   u32x4 acc = {0, 0, 0, 0};
-  for (uint64_t g = (uint64_t)blockIdx.x * (16 / G) + sub; g < nwin; g += (uint64_t)gridDim.x * (16 / G)) {
+  const uint32_t per_xcd = gridDim.x / 8;
+  const uint32_t blk = XCDMAP ? (blockIdx.x % 8) * per_xcd + blockIdx.x / 8 : blockIdx.x;
+  if (XCDMAP == 2) {
+    const uint64_t share = nwin / gridDim.x;  // windows of one workgroup, contiguous
+    for (uint64_t k = sub; k < share; k += 16 / G) {
+      const uint8_t* q = p + ((uint64_t)blk * share + k) * win + 2048 * wsub + 16 * lane;
+      u32x4 a = __builtin_nontemporal_load((gptr)q), b = __builtin_nontemporal_load((gptr)(q + 1024));
+      for (uint64_t o = kStripe; o < win; o += kStripe) {
+        const u32x4 na = __builtin_nontemporal_load((gptr)(q + o)), nb = __builtin_nontemporal_load((gptr)(q + o + 1024));
+        acc ^= a ^ b;
+        a = na;
+        b = nb;
+      }
+      acc ^= a ^ b;
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = 1;
+    return;
+  }
+  for (uint64_t g = (uint64_t)blk * (16 / G) + sub; g < nwin; g += (uint64_t)gridDim.x * (16 / G)) {
     const uint8_t* q = p + g * win + 2048 * wsub + 16 * lane;
     u32x4 a = __builtin_nontemporal_load((gptr)q), b = __builtin_nontemporal_load((gptr)(q + 1024));
     for (uint64_t o = kStripe; o < win; o += kStripe) {
@@ -356,6 +377,17 @@ int main(int argc, char** argv) {
     timeit("crc pattern G=2 (prefetch 1, nt)", bytes, [&] { read_crc_pattern<2><<<256, 1024>>>(d, nwin, win, out); });
     timeit("crc pattern G=4 (prefetch 1, nt)", bytes, [&] { read_crc_pattern<4><<<256, 1024>>>(d, nwin, win, out); });
     timeit("crc pattern G=8 (prefetch 1, nt)", bytes, [&] { read_crc_pattern<8><<<256, 1024>>>(d, nwin, win, out); });
+    return 0;
+  }
+  if (argc > 2 && !strcmp(argv[2], "xcd")) {   // does it matter which XCD reads which part of the batch?
+    for (int rep = 0; rep < 2; rep++) {
+      timeit("crc pattern G=8, workgroup b takes share b of every pass", bytes, [&] { read_crc_pattern<8, 0><<<256, 1024>>>(d, nwin, win, out); });
+      timeit("crc pattern G=8, XCD x takes eighth x of every pass", bytes, [&] { read_crc_pattern<8, 1><<<256, 1024>>>(d, nwin, win, out); });
+      timeit("crc pattern G=8, XCD x takes eighth x of the batch", bytes, [&] { read_crc_pattern<8, 2><<<256, 1024>>>(d, nwin, win, out); });
+      timeit("crc pattern G=2, workgroup b takes share b of every pass", bytes, [&] { read_crc_pattern<2, 0><<<256, 1024>>>(d, nwin, win, out); });
+      timeit("crc pattern G=2, XCD x takes eighth x of every pass", bytes, [&] { read_crc_pattern<2, 1><<<256, 1024>>>(d, nwin, win, out); });
+      timeit("crc pattern G=2, XCD x takes eighth x of the batch", bytes, [&] { read_crc_pattern<2, 2><<<256, 1024>>>(d, nwin, win, out); });
+    }
     return 0;
   }
   if (argc > 2 && !strcmp(argv[2], "rolling")) {   // request depth x kind of work between the requests, 512-byte windows, 8 lanes
