@@ -4,6 +4,9 @@
 //
 //   read path   ChunkInputStream.computeChecksumBoundaries / validator
 //               hadoop-hdds/client/src/main/java/org/apache/hadoop/hdds/scm/storage/ChunkInputStream.java:455-535
+//               and the datanode's cut of a ReadChunk response into buffers (what makes the V0 / V1 layouts):
+//               hadoop-hdds/container-service/src/main/java/org/apache/hadoop/ozone/container/keyvalue/interfaces/ChunkManager.java:107-134
+//               hadoop-hdds/common/src/main/java/org/apache/hadoop/ozone/common/utils/BufferUtils.java:42-63, 127-129
 //   scrubber    KeyValueContainerCheck.verifyChecksum
 //               hadoop-hdds/container-service/src/main/java/org/apache/hadoop/ozone/container/keyvalue/KeyValueContainerCheck.java:262-322
 //   write path  BlockOutputStream.writeChunkToContainer over BufferPool buffers
@@ -35,6 +38,51 @@ inline std::pair<long long, long long> computeChecksumBoundaries(long long start
   const long long adjustedChunkOffset = (startByteIndex / bytesPerChecksum) * bytesPerChecksum;
   const long long endIndex = ((endByteIndex / bytesPerChecksum) + 1) * bytesPerChecksum;  // exclusive
   return {adjustedChunkOffset, std::min(endIndex, chunkLength) - adjustedChunkOffset};
+}
+
+// ChunkManager.java:107-134: capacity of the buffers a datanode reads a chunk into -- the whole chunk for a client that
+// asked for one buffer (V0), else one buffer per bytes-per-checksum window so that each buffer corresponds to one
+// checksum (V1), the default capacity (ozone.chunk.read.buffer.default.size, 64 KiB) when the chunk carries no
+// checksums, and the whole chunk when that leaves 0.
+constexpr long long kChunkReadBufferDefaultSize = 64 * 1024;
+inline long long getBufferCapacityForChunkRead(const ChunkInfo& chunkInfo,
+                                               long long defaultReadBufferCapacity = kChunkReadBufferDefaultSize) {
+  long long bufferCapacity = 0;
+  if (chunkInfo.isReadDataIntoSingleBuffer()) {
+    bufferCapacity = chunkInfo.getLen();
+  } else if (chunkInfo.hasChecksumData()) {
+    const ChecksumData& c = chunkInfo.getChecksumData();
+    bufferCapacity = c.getChecksumType() == ChecksumType::NONE ? defaultReadBufferCapacity : c.getBytesPerChecksum();
+  }
+  if (bufferCapacity == 0) bufferCapacity = chunkInfo.getLen();
+  return bufferCapacity;
+}
+
+// BufferUtils.java:42-63: lengths of the buffers that hold totalLen bytes -- all of bufferCapacity bytes but the last,
+// which takes what remains.
+inline std::vector<long long> assignByteBuffers(long long totalLen, long long bufferCapacity) {
+  if (totalLen <= 0) throw std::invalid_argument("Buffer Length should be a positive integer.");
+  if (bufferCapacity <= 0) throw std::invalid_argument("Buffer Capacity should be a positive integer.");
+  const long long numBuffers = (totalLen + bufferCapacity - 1) / bufferCapacity;
+  std::vector<long long> lens((size_t)(numBuffers - 1), bufferCapacity);
+  lens.push_back(totalLen - bufferCapacity * (numBuffers - 1));
+  return lens;
+}
+
+// The bytes of a chunk (or of the requested range of it) cut the way FilePerBlockStrategy.readChunk returns them
+// (FilePerBlockStrategy.java:150-173): one element for a V0 client, one per window otherwise; an empty chunk gives one
+// empty buffer.
+inline std::vector<ByteString> readChunkBuffers(const ByteString& chunkData, const ChunkInfo& chunkInfo,
+                                                long long defaultReadBufferCapacity = kChunkReadBufferDefaultSize) {
+  if (chunkData.empty()) return {ByteString()};
+  std::vector<ByteString> out;
+  size_t pos = 0;
+  for (long long n : assignByteBuffers((long long)chunkData.size(),
+                                       getBufferCapacityForChunkRead(chunkInfo, defaultReadBufferCapacity))) {
+    out.push_back(chunkData.substr(pos, (size_t)n));
+    pos += (size_t)n;
+  }
+  return out;
 }
 
 // The ReadChunk response validator (ChunkInputStream.java:455-504).  chunkOffset / checksumData describe the

@@ -355,6 +355,10 @@ class ChunkInfo {
   long long getLen() const { return len_; }
   const ChecksumData& getChecksumData() const { return checksumData_; }
   void setChecksumData(const ChecksumData& c) { checksumData_ = c; hasChecksum_ = true; }
+  bool hasChecksumData() const { return hasChecksum_; }  // the Java field is null until setChecksumData
+  // ChunkInfo.java:41-44, 190-196: set for older clients, whose ReadChunk responses hold all data in one buffer (V0)
+  void setReadDataIntoSingleBuffer(bool v) { readDataIntoSingleBuffer_ = v; }
+  bool isReadDataIntoSingleBuffer() const { return readDataIntoSingleBuffer_; }
   const std::map<std::string, std::string>& getMetadata() const { return metadata_; }
 
   // ChunkInfo.java:108-133: fields in number order, metadata in key order (a TreeMap), a missing ChecksumData
@@ -442,6 +446,7 @@ class ChunkInfo {
   long long offset_, len_;
   ChecksumData checksumData_;
   bool hasChecksum_;
+  bool readDataIntoSingleBuffer_ = false;
   std::map<std::string, std::string> metadata_;
 };
 

@@ -5,8 +5,14 @@
   validate                    :455-504  the validator run on every ReadChunk response: length check, start index,
                                         Checksum.verifyChecksum (here: one GPU call for all windows of the response,
                                         without the per-window copy of ChecksumByteBufferImpl.java:42-46)
+
+and the datanode side that shapes what the validator receives (the V0 / V1 layouts of a ReadChunk response):
+
+  getBufferCapacityForChunkRead   hadoop-hdds/container-service/.../keyvalue/interfaces/ChunkManager.java:107-134
+  assignByteBuffers               hadoop-hdds/common/.../ozone/common/utils/BufferUtils.java:42-63, 127-129
+  readChunkBuffers                the cut FilePerBlockStrategy.readChunk makes (FilePerBlockStrategy.java:163-173)
 """
-from .checksum import Checksum, OzoneChecksumException
+from .checksum import Checksum, ChecksumType, OzoneChecksumException
 
 
 def computeChecksumBoundaries(startByteIndex, dataLen, bytesPerChecksum, chunkLength):
@@ -36,3 +42,50 @@ def validate(chunkName, chunkOffset, checksumData, reqOffset, reqLen, data=None,
         startIndex = int(relativeOffset // checksumData.getBytesPerChecksum())
         Checksum.verifyChecksum(byteStrings, checksumData, startIndex, isV0)
     return True
+
+
+
+OZONE_CHUNK_READ_BUFFER_DEFAULT_SIZE = 64 * 1024   # ozone.chunk.read.buffer.default.size
+
+
+def getBufferCapacityForChunkRead(chunkInfo, defaultReadBufferCapacity=OZONE_CHUNK_READ_BUFFER_DEFAULT_SIZE):
+    """Capacity of the buffers a datanode reads a chunk into: the whole chunk for a client that asked for one buffer
+    (V0), else one buffer per bytes-per-checksum window so that each buffer corresponds to one checksum (V1) -- the
+    default capacity when the chunk carries no checksums -- and the whole chunk when that leaves 0."""
+    bufferCapacity = 0
+    if chunkInfo.readDataIntoSingleBuffer:
+        bufferCapacity = chunkInfo.getLen()
+    else:
+        checksumData = chunkInfo.getChecksumData()
+        if checksumData is not None:
+            if checksumData.getChecksumType() == ChecksumType.NONE:
+                bufferCapacity = defaultReadBufferCapacity
+            else:
+                bufferCapacity = checksumData.getBytesPerChecksum()
+    if bufferCapacity == 0:
+        bufferCapacity = chunkInfo.getLen()
+    return bufferCapacity
+
+
+def assignByteBuffers(totalLen, bufferCapacity):
+    """Lengths of the buffers that hold totalLen bytes: ceil(totalLen / bufferCapacity) of them, all of
+    bufferCapacity bytes but the last, which takes what remains."""
+    if totalLen <= 0:
+        raise ValueError("Buffer Length should be a positive integer.")
+    if bufferCapacity <= 0:
+        raise ValueError("Buffer Capacity should be a positive integer.")
+    numBuffers = -(-totalLen // bufferCapacity)
+    return [bufferCapacity] * (numBuffers - 1) + [totalLen - bufferCapacity * (numBuffers - 1)]
+
+
+def readChunkBuffers(chunkData, chunkInfo, defaultReadBufferCapacity=OZONE_CHUNK_READ_BUFFER_DEFAULT_SIZE):
+    """The bytes of a chunk (or of the requested range of it) cut the way a datanode returns them: a list with one
+    element for a V0 client, one element per window otherwise.  An empty chunk gives one empty buffer
+    (FilePerBlockStrategy.java:150-153)."""
+    if len(chunkData) <= 0:
+        return [bytes(chunkData)]
+    out, pos = [], 0
+    for n in assignByteBuffers(len(chunkData), getBufferCapacityForChunkRead(chunkInfo, defaultReadBufferCapacity)):
+        out.append(bytes(chunkData[pos:pos + n]))
+        pos += n
+    return out

@@ -122,6 +122,32 @@ int main() {
     } catch (const OzoneChecksumException& e) { EXPECT(e.index() == 1); }
   }
 
+  // ---- the datanode's cut of a response into buffers (ChunkManager.java:107-134, BufferUtils.java:42-63) ----
+  {
+    ChunkInfo info("chunk1", 0, 100);
+    info.setChecksumData(cd);                                     // CRC32 at 20 bytes per checksum
+    EXPECT(getBufferCapacityForChunkRead(info) == 20);            // one buffer per checksum
+    EXPECT(assignByteBuffers(90, 20) == (std::vector<long long>{20, 20, 20, 20, 10}));
+    const auto range = computeChecksumBoundaries(25, 30, 20, 100);
+    const std::string resp = whole.substr((size_t)range.first, (size_t)range.second);
+    const std::vector<ByteString> v1 = readChunkBuffers(resp, info);
+    EXPECT(v1.size() == 2 && v1[0].size() == 20 && v1[1].size() == 20);
+    validateReadChunk("chunk1", 0, cd, range.first, range.second, v1, false);
+    info.setReadDataIntoSingleBuffer(true);                       // an older client: everything in one buffer
+    EXPECT(getBufferCapacityForChunkRead(info) == 100);
+    const std::vector<ByteString> v0 = readChunkBuffers(resp, info);
+    EXPECT(v0.size() == 1 && v0[0] == resp);
+    validateReadChunk("chunk1", 0, cd, range.first, range.second, v0, true);
+    ChunkInfo none("n", 0, 200000);
+    none.setChecksumData(ChecksumData(ChecksumType::NONE, 0));
+    EXPECT(getBufferCapacityForChunkRead(none) == 64 * 1024);     // no checksums: the default capacity
+    EXPECT(assignByteBuffers(200000, 65536) == (std::vector<long long>{65536, 65536, 65536, 3392}));
+    ChunkInfo bare("b", 0, 77);                                   // no checksum data at all: one buffer
+    EXPECT(getBufferCapacityForChunkRead(bare) == 77);
+    EXPECT(readChunkBuffers(ByteString(), info).size() == 1);
+    try { assignByteBuffers(0, 4); EXPECT(!"zero length accepted"); } catch (const std::invalid_argument&) {}
+  }
+
   // ---- ChunkInfo wire form (ChunkInfo.java:88-133, DatanodeClientProtocol.proto:366-372) ----
   {
     const ChecksumData cd(ChecksumType::CRC32, 1 << 20, {ByteString("\x01\x02\x03\x04", 4), ByteString("\xff\xfe\xfd\xfc", 4)});

@@ -30,6 +30,57 @@ def test_validate_length_check_needs_no_gpu():
     assert read_path.validate("c1", 0, cd, 20, 40, data=b"x" * 40, verifyChecksum=False)   # ozone.client.verify.checksum=false
 
 
+def test_datanode_read_buffers_follow_the_checksum_windows():
+    # ChunkManager.getBufferCapacityForChunkRead + BufferUtils.assignByteBuffers: what decides the V0 / V1 layout
+    from hadoop_ozone_amd.checksum import ChunkInfo
+    info = ChunkInfo("c", 0, 100)
+    info.setChecksumData(ChecksumData(ChecksumType.CRC32, 20, [b"\0" * 4] * 5))
+    assert read_path.getBufferCapacityForChunkRead(info) == 20                      # one buffer per checksum
+    assert read_path.assignByteBuffers(100, 20) == [20] * 5
+    assert read_path.assignByteBuffers(90, 20) == [20, 20, 20, 20, 10]              # the last takes what remains
+    assert [len(b) for b in read_path.readChunkBuffers(b"x" * 90, info)] == [20, 20, 20, 20, 10]
+    info.readDataIntoSingleBuffer = True                                            # an older client: one buffer
+    assert read_path.getBufferCapacityForChunkRead(info) == 100
+    assert [len(b) for b in read_path.readChunkBuffers(b"x" * 100, info)] == [100]
+    none = ChunkInfo("n", 0, 200000)
+    none.setChecksumData(ChecksumData(ChecksumType.NONE, 0, []))
+    assert read_path.getBufferCapacityForChunkRead(none) == 64 * 1024               # no checksums: the default capacity
+    assert read_path.assignByteBuffers(200000, 64 * 1024) == [65536, 65536, 65536, 3392]
+    bare = ChunkInfo("b", 0, 77)                                                    # no checksum data at all: one buffer
+    bare.checksumData = None
+    assert read_path.getBufferCapacityForChunkRead(bare) == 77
+    assert read_path.readChunkBuffers(b"", info) == [b""]
+    for bad in ((0, 4), (4, 0)):
+        with pytest.raises(ValueError):
+            read_path.assignByteBuffers(*bad)
+
+
+@pytest.mark.gpu
+def test_validate_takes_what_a_datanode_returns():
+    # a chunk of 5 windows and a ragged sixth, read in part: the range is widened to window boundaries on the client,
+    # cut into one buffer per window on the datanode, and verified from the window the range starts in
+    from hadoop_ozone_amd.checksum import ChunkInfo
+    bpc, n = 4096, 5 * 4096 + 1000
+    whole = oracle.splitmix64(77, n).tobytes()
+    cd = ChecksumData(ChecksumType.CRC32C, bpc, [oracle.compute(oracle.CRC32C, bpc, whole[i:i + bpc]) for i in range(0, n, bpc)])
+    info = ChunkInfo("c", 8192, n)
+    info.setChecksumData(cd)
+    for start, length in ((0, n), (5000, 9000), (4 * 4096 + 7, 5000), (n - 10, 10)):
+        off, ln = read_path.computeChecksumBoundaries(start, length, bpc, n)
+        bufs = read_path.readChunkBuffers(whole[off:off + ln], info)
+        assert all(len(b) == bpc for b in bufs[:-1]) and 0 < len(bufs[-1]) <= bpc
+        assert read_path.validate("c", info.getOffset(), cd, info.getOffset() + off, ln, dataBuffers=bufs)
+        info.readDataIntoSingleBuffer = True
+        (one,) = read_path.readChunkBuffers(whole[off:off + ln], info)
+        assert read_path.validate("c", info.getOffset(), cd, info.getOffset() + off, ln, data=one)
+        info.readDataIntoSingleBuffer = False
+        if len(bufs) >= 2:
+            bad = list(bufs)
+            bad[1] = bytes([bad[1][0] ^ 4]) + bad[1][1:]
+            with pytest.raises(OzoneChecksumException, match="Checksum mismatch at index 1"):
+                read_path.validate("c", info.getOffset(), cd, info.getOffset() + off, ln, dataBuffers=bad)
+
+
 def test_scrubber_message_formats():
     assert scrubber._java_bytes(b"\x00\x7f\x80\xff") == "[0, 127, -128, -1]"
     assert scrubber.chunk_info_str("blk_1_chunk_1", 0, 3072) == "ChunkInfo{chunkName='blk_1_chunk_1, offset=0, len=3072}"
