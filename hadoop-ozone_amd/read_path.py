@@ -11,6 +11,12 @@ and the datanode side that shapes what the validator receives (the V0 / V1 layou
   getBufferCapacityForChunkRead   hadoop-hdds/container-service/.../keyvalue/interfaces/ChunkManager.java:107-134
   assignByteBuffers               hadoop-hdds/common/.../ozone/common/utils/BufferUtils.java:42-63, 127-129
   readChunkBuffers                the cut FilePerBlockStrategy.readChunk makes (FilePerBlockStrategy.java:163-173)
+
+and what the client does with the validator's verdict:
+
+  readChunkWithFailover           the loop over a pipeline's datanodes of XceiverClientGrpc.sendCommandWithRetry
+                                  (hadoop-hdds/client/.../hdds/scm/XceiverClientGrpc.java:368-418): an IOException from a
+                                  validator -- a checksum mismatch is one -- sends the read to the next replica
 """
 from .checksum import Checksum, ChecksumType, OzoneChecksumException
 
@@ -89,3 +95,25 @@ def readChunkBuffers(chunkData, chunkInfo, defaultReadBufferCapacity=OZONE_CHUNK
         out.append(bytes(chunkData[pos:pos + n]))
         pos += n
     return out
+
+
+def readChunkWithFailover(datanodes, sendCommand, validators=()):
+    """Asks the datanodes of a pipeline in turn until one answers with a response every validator accepts.
+
+    sendCommand(dn) -> response; validators are callables of the response that raise IOError (OzoneChecksumException
+    is one) to reject it.  Returns (response, datanodes tried in order).  When every datanode fails, the LAST
+    datanode's exception is raised, as the reference keeps only the latest (`ioException = e`)."""
+    ioException = None
+    tried = []
+    for dn in datanodes:
+        tried.append(dn)
+        try:
+            response = sendCommand(dn)
+            for validator in validators:
+                validator(response)
+            return response, tried
+        except IOError as e:
+            ioException = e
+    if ioException is None:
+        raise ValueError("no datanode to read from")   # Preconditions.checkNotNull(ioException)
+    raise ioException
