@@ -103,7 +103,7 @@ def nt_read_ceiling(gib):
         return {"measured_in_this_run": False, "note": "tools/hbm_read_bench failed (rc %d): %s" % (r.returncode, (r.stdout + r.stderr)[-200:])}
     top = max(pats, key=lambda k: pats[k]["avg_GBps"])
     return {"GBps": pats[top]["avg_GBps"], "pattern": "wavefronts per window " + top, "patterns": pats, "buffer_GiB": gib,
-            "source": "tools/hbm_read_bench %d crc, child process, 10 launches after 3 warm-ups per pattern" % gib,
+            "source": "tools/hbm_read_bench %d crc, child process, 20 launches after 10 warm-ups per pattern" % gib,
             "measured_in_this_run": True}
 
 

@@ -278,6 +278,24 @@ __device__ __forceinline__ void emit(const CrcLaunch& p, uint64_t g, uint64_t ch
   }
 }
 
+// Verify, in two halves, for kernels that know a window's place long before its digest: the stored digest is requested
+// first (stored[startIndex + i], ChecksumData.verifyChecksumDataMatches) and compared when the computed one exists, so
+// that the request's latency passes behind the window's own loads instead of in front of the next window's.
+struct Stored {
+  uint32_t value;
+  bool missing;  // startIndex + i lies beyond the stored list
+};
+__device__ __forceinline__ Stored stored_digest(const CrcLaunch& p, uint64_t chunk, uint64_t wi) {
+  const uint64_t si = p.start_index + wi;
+  if (si >= p.n_expected) return Stored{0u, true};
+  const uint8_t* ex = p.expected + chunk * p.expected_stride + si * 4;
+  if ((reinterpret_cast<uintptr_t>(ex) & 3) == 0) return Stored{*reinterpret_cast<const uint32_t*>(ex), false};
+  return Stored{(uint32_t)ex[0] | ((uint32_t)ex[1] << 8) | ((uint32_t)ex[2] << 16) | ((uint32_t)ex[3] << 24), false};
+}
+__device__ __forceinline__ void judge(const CrcLaunch& p, uint64_t chunk, uint64_t wi, const Stored& st, uint32_t be) {
+  if (st.missing || st.value != be) atomicMin(p.first_mismatch + chunk, (unsigned long long)wi);
+}
+
 // Finishes a window: the bytes behind its last 16-byte boundary (or all of a tiny window) bit-serially,
 // then getValue() and Ints.toByteArray.
 __device__ __forceinline__ uint32_t finish_window(uint32_t state, bool vec, uintptr_t s, uintptr_t e16, uintptr_t e, uint32_t poly) {
@@ -691,6 +709,18 @@ __global__ __launch_bounds__(kThreads) void crc_flat_kernel(const CrcLaunch p) {
        w0 += (uint64_t)gridDim.x * kWaves * kWinPerWave) {
     const uint64_t ga = w0 + grp, gb = w0 + kWinPerRow + grp;
     const uintptr_t wa = base + (ga < last ? ga : last) * p.bpc, wb = base + (gb < last ? gb : last) * p.bpc;
+    uint64_t chunk_a = 0, wi_a = 0, chunk_b = 0, wi_b = 0;
+    Stored st_a = {0u, false}, st_b = {0u, false};
+    if (MODE == kModeVerify && sl == LPW - 1) {  // the lanes that will hold the windows' registers
+      if (ga <= last) {
+        split_window(p, ga, chunk_a, wi_a);
+        st_a = stored_digest(p, chunk_a, wi_a);
+      }
+      if (gb <= last) {
+        split_window(p, gb, chunk_b, wi_b);
+        st_b = stored_digest(p, chunk_b, wi_b);
+      }
+    }
     uint4 ca[UNR], cb[UNR], na[UNR], nb[UNR];
     Acc4 a, b;
     Acc4 ta = {0, 0, 0, 0}, tb = {0, 0, 0, 0};  // PH > 1: the accumulators of the tail, parked at the wrap
@@ -830,15 +860,8 @@ __global__ __launch_bounds__(kThreads) void crc_flat_kernel(const CrcLaunch p) {
         if (ga <= last) out[ga] = __builtin_bswap32(~x);
         if (gb <= last) out[gb] = __builtin_bswap32(~y);
       } else {
-        uint64_t chunk, wi;
-        if (ga <= last) {
-          split_window(p, ga, chunk, wi);
-          emit<MODE>(p, ga, chunk, wi, __builtin_bswap32(~x));
-        }
-        if (gb <= last) {
-          split_window(p, gb, chunk, wi);
-          emit<MODE>(p, gb, chunk, wi, __builtin_bswap32(~y));
-        }
+        if (ga <= last) judge(p, chunk_a, wi_a, st_a, __builtin_bswap32(~x));
+        if (gb <= last) judge(p, chunk_b, wi_b, st_b, __builtin_bswap32(~y));
       }
     }
   }

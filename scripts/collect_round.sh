@@ -13,6 +13,7 @@ H=$((64*256*MIB));
 python scripts/summarize_pmc.py headline CRC32-1048576-64 crc_windows_kernel $((H + 64*256*4)) 10
 python scripts/summarize_pmc.py cfg3 CRC32C-16384-64 crc_flat_kernel $((H + H/16384*4 + H/4194304*8)) 11
 python scripts/summarize_pmc.py cfg4 SHA256-1048576-128 sha256_split_windows_kernel $((2*H + 2*H/MIB*32)) 1 $((2*H/MIB/64*16385))
+python scripts/summarize_pmc.py md51m MD5-1048576-128 digest_windows_kernel $((2*H + 2*H/MIB*16)) 1 $((2*H/MIB/64*16385))
 python scripts/summarize_pmc.py sha16k SHA256-16384-32 digest_windows_kernel $((H/2 + H/2/16384*32)) 10 $((H/2/16384/64*257))
 python scripts/summarize_pmc.py md516k MD5-16384-32 digest_windows_kernel $((H/2 + H/2/16384*16)) 10 $((H/2/16384/64*257))
 python scripts/summarize_pmc.py flat512 CRC32-512-64 crc_flat_kernel $((H + H/512*4)) 10

@@ -272,6 +272,12 @@ __global__ __launch_bounds__(1024) void read_flat_rolling(const uint8_t* p, uint
       } else if (WORK & 256) {  // write-through, streaming
         asm volatile("global_store_dword %0, %1, off sc0 sc1 nt" : : "v"(digests + w0 + grp), "v"(acc.x) : "memory");
         asm volatile("global_store_dword %0, %1, off sc0 sc1 nt" : : "v"(digests + w0 + kPerRow + grp), "v"(acc2.x) : "memory");
+      } else if (WORK & 1024) {  // the same volume, but every wavefront writes one contiguous stream of its own (32 KiB
+                                 // per wavefront, 512 KiB per workgroup: one page per CU as far as address translation goes)
+        const uint64_t it = w0 / step;
+        uint32_t* mine = digests + ((uint64_t)blockIdx.x * 16 + wave) * (nwin / ((uint64_t)gridDim.x * 16)) + it * 2 * kPerRow;
+        mine[grp] = acc.x;
+        mine[kPerRow + grp] = acc2.x;
       } else if (WORK & 512) {  // device scope
         asm volatile("global_store_dword %0, %1, off sc1" : : "v"(digests + w0 + grp), "v"(acc.x) : "memory");
         asm volatile("global_store_dword %0, %1, off sc1" : : "v"(digests + w0 + kPerRow + grp), "v"(acc2.x) : "memory");
@@ -341,14 +347,15 @@ __global__ __launch_bounds__(1024) void read_block_windows(const uint8_t* p, uin
   if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = 1;
 }
 
+static int g_warmups = 3, g_reps = 10;  // launches in front of the timed ones, timed launches
 template <class F>
 static void timeit(const char* name, uint64_t bytes, F f) {
   hipEvent_t a, b;
   CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-  for (int i = 0; i < 3; i++) f();
+  for (int i = 0; i < g_warmups; i++) f();
   CK(hipDeviceSynchronize());
   float best = 1e30f, sum = 0;
-  const int reps = 10;
+  const int reps = g_reps;
   for (int i = 0; i < reps; i++) {
     CK(hipEventRecord(a)); f(); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
     float ms; CK(hipEventElapsedTime(&ms, a, b));
@@ -373,6 +380,8 @@ int main(int argc, char** argv) {
   const u32x4* p = (const u32x4*)d;
   printf("buffer %llu GiB\n", (unsigned long long)(bytes >> 30));
   if (argc > 2 && !strcmp(argv[2], "crc")) {   // only the 1 MiB-window CRC kernel's own pattern, for bench.py's ceiling line
+    g_warmups = 10;                              // as bench.py times the kernel: twenty launches after ten
+    g_reps = 20;
     timeit("crc pattern G=1 (prefetch 1, nt)", bytes, [&] { read_crc_pattern<1><<<256, 1024>>>(d, nwin, win, out); });
     timeit("crc pattern G=2 (prefetch 1, nt)", bytes, [&] { read_crc_pattern<2><<<256, 1024>>>(d, nwin, win, out); });
     timeit("crc pattern G=4 (prefetch 1, nt)", bytes, [&] { read_crc_pattern<4><<<256, 1024>>>(d, nwin, win, out); });
@@ -403,6 +412,7 @@ int main(int argc, char** argv) {
     ROLL(1, 21, "LDS lookups + digest stores that stay in the L2") ROLL(4, 21, "LDS lookups + digest stores that stay in the L2")
     ROLL(1, 37, "LDS lookups + non-temporal digest stores") ROLL(4, 37, "LDS lookups + non-temporal digest stores")
     ROLL(1, 133, "LDS lookups + digest stores sc0 sc1") ROLL(1, 261, "LDS lookups + digest stores sc0 sc1 nt") ROLL(1, 517, "LDS lookups + digest stores sc1")
+    ROLL(1, 1029, "LDS lookups + digest stores, one contiguous stream per wavefront") ROLL(4, 1029, "LDS lookups + digest stores, one contiguous stream per wavefront")
     ROLL(1, 69, "LDS lookups + digest stores every fourth group, whole lines") ROLL(4, 69, "LDS lookups + digest stores every fourth group, whole lines")
     ROLL(1, 9, "LDS lookups + serial fold") ROLL(2, 9, "LDS lookups + serial fold") ROLL(4, 9, "LDS lookups + serial fold")
     ROLL(1, 13, "LDS lookups + serial fold + digest stores") ROLL(2, 13, "LDS lookups + serial fold + digest stores")
