@@ -299,6 +299,65 @@ __global__ __launch_bounds__(1024) void read_flat_rolling(const uint8_t* p, uint
   if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = lds[5];
 }
 
+// The rolling pattern (one stripe group in flight, LDS lookups) with the digests of KB consecutive window groups kept in
+// registers and stored together: every workgroup does the same work from the same start, so without any synchronisation
+// the workgroups' store bursts fall close together in time.  SC1: write-through stores (the burst reaches DRAM when it is
+// issued, not when the L2 happens to evict the lines).
+template <int KB, bool SC1>
+__global__ __launch_bounds__(1024) void read_flat_store_bursts(const uint8_t* p, uint64_t nwin, uint32_t* out, uint32_t* digests) {
+  __shared__ char lds[157696];
+  for (int i = threadIdx.x; i < 131072 / 4; i += 1024) reinterpret_cast<uint32_t*>(lds)[i] = i * 2654435761u;
+  __syncthreads();
+  constexpr int LPW = 8, NST = 4;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  constexpr int kPerRow = 64 / LPW;
+  constexpr uint32_t kStripe = 16u * LPW, kWin = kStripe * NST;
+  const int sl = lane & (LPW - 1), grp = lane / LPW;
+  const uint32_t lane4 = (lane & 31) * 4u;
+  const uint64_t step = (uint64_t)gridDim.x * 16 * 2 * kPerRow;
+  uint64_t w0 = ((uint64_t)blockIdx.x * 16 + wave) * 2 * kPerRow;
+  auto row = [&](uint64_t w, int r) { uint64_t g = w + r * kPerRow + grp; if (g >= nwin) g = nwin - 1; return p + g * kWin + 16 * sl; };
+  const uint8_t *wa = row(w0, 0), *wb = row(w0, 1);
+  u32x4 qa[NST], qb[NST];
+  ld_async(qa[0], wa); ld_async(qb[0], wb);
+  u32x4 acc = {0, 0, 0, 0}, acc2 = {1, 2, 3, 4};
+  while (w0 < nwin) {   // nwin is a multiple of KB * step in this tool's runs
+    uint32_t da[KB], db[KB];
+    const uint64_t first = w0;
+#pragma unroll
+    for (int k = 0; k < KB; k++, w0 += step) {
+      const uint8_t *na = row(w0 + step, 0), *nb = row(w0 + step, 1);
+#pragma unroll
+      for (int s = 0; s < NST; s++) {
+        const int t = s + 1;
+        if (t < NST) { ld_async(qa[t], wa + t * kStripe); ld_async(qb[t], wb + t * kStripe); }
+        else { ld_async(qa[0], na); ld_async(qb[0], nb); }
+        wait_vm<2>(qa[s], qb[s]);
+        unit_work<1>(lds, lane4, acc, qa[s]);
+        unit_work<1>(lds, lane4, acc2, qb[s]);
+      }
+      da[k] = acc.x; db[k] = acc2.x;
+      wa = na; wb = nb;
+    }
+    if (sl == LPW - 1) {
+#pragma unroll
+      for (int k = 0; k < KB; k++) {
+        uint32_t* d0 = digests + first + k * step + grp;
+        if (SC1) {
+          asm volatile("global_store_dword %0, %1, off sc1" : : "v"(d0), "v"(da[k]) : "memory");
+          asm volatile("global_store_dword %0, %1, off sc1" : : "v"(d0 + kPerRow), "v"(db[k]) : "memory");
+        } else {
+          d0[0] = da[k];
+          d0[kPerRow] = db[k];
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  acc ^= acc2;
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = lds[5];
+}
+
 // the same with ROWS 1 KiB rows per wavefront and stripe, and PF stripes ahead
 template <int G, int ROWS, int PF>
 __global__ __launch_bounds__(1024) void read_crc_rows(const uint8_t* p, uint64_t nwin, uint64_t win, uint32_t* out) {
@@ -413,6 +472,12 @@ int main(int argc, char** argv) {
     ROLL(1, 37, "LDS lookups + non-temporal digest stores") ROLL(4, 37, "LDS lookups + non-temporal digest stores")
     ROLL(1, 133, "LDS lookups + digest stores sc0 sc1") ROLL(1, 261, "LDS lookups + digest stores sc0 sc1 nt") ROLL(1, 517, "LDS lookups + digest stores sc1")
     ROLL(1, 1029, "LDS lookups + digest stores, one contiguous stream per wavefront") ROLL(4, 1029, "LDS lookups + digest stores, one contiguous stream per wavefront")
+    timeit("512 B windows, 8 lanes, LDS lookups + digest stores in bursts of 8 groups", bytes, [&] { read_flat_store_bursts<8, false><<<256, 1024>>>(d, nw, out, dig); });
+    timeit("512 B windows, 8 lanes, LDS lookups + digest stores in bursts of 8 groups, sc1", bytes, [&] { read_flat_store_bursts<8, true><<<256, 1024>>>(d, nw, out, dig); });
+    timeit("512 B windows, 8 lanes, LDS lookups + digest stores in bursts of 16 groups", bytes, [&] { read_flat_store_bursts<16, false><<<256, 1024>>>(d, nw, out, dig); });
+    timeit("512 B windows, 8 lanes, LDS lookups + digest stores in bursts of 16 groups, sc1", bytes, [&] { read_flat_store_bursts<16, true><<<256, 1024>>>(d, nw, out, dig); });
+    timeit("512 B windows, 8 lanes, LDS lookups + digest stores in bursts of 32 groups", bytes, [&] { read_flat_store_bursts<32, false><<<256, 1024>>>(d, nw, out, dig); });
+    timeit("512 B windows, 8 lanes, LDS lookups + digest stores in bursts of 32 groups, sc1", bytes, [&] { read_flat_store_bursts<32, true><<<256, 1024>>>(d, nw, out, dig); });
     ROLL(1, 69, "LDS lookups + digest stores every fourth group, whole lines") ROLL(4, 69, "LDS lookups + digest stores every fourth group, whole lines")
     ROLL(1, 9, "LDS lookups + serial fold") ROLL(2, 9, "LDS lookups + serial fold") ROLL(4, 9, "LDS lookups + serial fold")
     ROLL(1, 13, "LDS lookups + serial fold + digest stores") ROLL(2, 13, "LDS lookups + serial fold + digest stores")
