@@ -22,8 +22,13 @@
  *                    published algorithms are restated here).
  *
  * Pinned by: tests/test_oracle.py against tests/golden/ (table digests of the
- * reference's own Java tables, CRC/SHA/MD5 known-answer vectors, and vectors
- * produced by zlib / hashlib).
+ * reference's own Java tables, CRC/SHA/MD5 known-answer vectors, vectors
+ * produced by zlib / hashlib, and for SHA-256 the one literal digest of known
+ * content that a test of the reference holds for the same MessageDigest,
+ * hadoop-ozone/s3gateway/src/test/java/org/apache/hadoop/ozone/s3/signature/
+ * TestStringToSignProducer.java:86).  MD5: parity unpinned by the reference --
+ * no test of it holds an MD5 digest of known content; RFC 1321 vectors and
+ * hashlib only.
  */
 #ifndef OZCS_ORACLE_H
 #define OZCS_ORACLE_H

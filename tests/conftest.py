@@ -45,3 +45,11 @@ def vectors():
 def reference_tables():
     with open(os.path.join(GOLDEN, "reference_tables.json")) as f:
         return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def reference_held():
+    """Digests the reference's own tests hold as literals for the JDK primitive this path uses
+    (tests/golden/gen_reference_held.py)."""
+    with open(os.path.join(GOLDEN, "reference_held_digests.json")) as f:
+        return json.load(f)

@@ -13,8 +13,9 @@ Sources of truth, all independent of this repository's oracle and kernels:
                  (the reference proves this equal to java.util.zip.CRC32C in
                  TestChecksumImplsComputeSameValues.java:59-79), plus RFC 3720 B.4 vectors.
   * SHA-256/MD5: Python hashlib (FIPS 180-4 / RFC 1321, what MessageDigest implements,
-                 Checksum.java:46-60,83-84).  The reference's own tests hold no literal digest
-                 for these, so they are pinned by the public standard only.
+                 Checksum.java:46-60,83-84).  The tests of the checksum path hold no literal digest
+                 for these; the one SHA-256 literal another test of the reference holds for the same
+                 MessageDigest is handled by gen_reference_held.py.
   * reference_tables.json holds only SHA-256 digests (and four sample entries) of the two Java
     tables, never the tables: enough to prove that a regenerated table is identical.
 

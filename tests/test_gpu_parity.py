@@ -56,6 +56,31 @@ def test_kat(gpu, vectors):
         assert got.hex() == "".join(rec["sums_hex"]), rec["name"]
 
 
+def test_sha256_equals_the_literal_a_reference_test_holds(gpu, reference_held):
+    # the one digest of known content that the reference's own tests hold for java.security.MessageDigest
+    # (TestStringToSignProducer.java:86, computed there by StringToSignProducer.hash): through the host-pointer call,
+    # as the ragged last window of a chunk, through the mirror of Checksum, and 300 times over in one device-resident
+    # launch (full wavefronts of the one-lane-per-window kernel)
+    torch, native, L = gpu
+    from hadoop_ozone_amd import Checksum, ChecksumType
+    for rec in reference_held:
+        t = getattr(native, rec["type"])
+        msg = np.frombuffer(rec["message_utf8"].encode("utf-8"), dtype=np.uint8)
+        want = bytes.fromhex(rec["digest_hex"])
+        assert native.compute(t, len(msg), msg) == want, rec["held_by"]
+        assert native.compute(t, 1 << 20, msg) == want
+        two = np.concatenate([np.zeros(256, dtype=np.uint8), msg])
+        assert native.compute(t, 256, two)[32:] == want
+        cd = Checksum(getattr(ChecksumType, rec["type"]), 4096).computeChecksum(msg.tobytes())
+        assert cd.getChecksums() == [want]
+        n, stride = 300, (len(msg) + 15) // 16 * 16 + 16
+        host = np.zeros(n * stride, dtype=np.uint8)
+        for c in range(n):
+            host[c * stride: c * stride + len(msg)] = msg
+        got = dev_compute(gpu, t, len(msg), torch.from_numpy(host).cuda(), len(msg), n, stride)
+        assert got == want * n
+
+
 def test_compute_golden(gpu, vectors):
     _, native, _ = gpu
     for rec in vectors["compute"]:

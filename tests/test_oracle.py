@@ -3,7 +3,9 @@
 The reference's own tests hold no literal digests for this path (they assert equality between
 implementations, TestChecksumImplsComputeSameValues.java:43-101, and structure, TestChecksum.java:47-80),
 so the oracle is pinned by: the digests of the reference's two Java CRC tables, published known-answer
-vectors, and vectors produced by zlib / hashlib / the parsed Java CRC32C table (tests/golden/gen_golden.py).
+vectors, vectors produced by zlib / hashlib / the parsed Java CRC32C table (tests/golden/gen_golden.py), and -- for
+SHA-256 -- the one literal digest of known content that another test of the reference holds for the same JDK
+primitive (tests/golden/gen_reference_held.py).
 """
 import hashlib
 import struct
@@ -24,6 +26,19 @@ def test_tables_equal_reference_java_tables(reference_tables):
         assert hashlib.sha256(struct.pack("<2048I", *t)).hexdigest() == rec["sha256"]
         for idx, val in rec["samples"].items():
             assert t[int(idx)] == int(val, 16)
+
+
+def test_sha256_equals_the_literal_a_reference_test_holds(reference_held):
+    # TestStringToSignProducer.java:86 asserts MessageDigest SHA-256 of a canonical request; the same message through
+    # the oracle, as one window and as the ragged last window of a chunk
+    for rec in reference_held:
+        t = getattr(oracle, rec["type"])
+        msg = np.frombuffer(rec["message_utf8"].encode("utf-8"), dtype=np.uint8)
+        assert hashlib.sha256(msg.tobytes()).hexdigest() == rec["digest_hex"]
+        assert oracle.compute(t, len(msg), msg).hex() == rec["digest_hex"], rec["held_by"]
+        assert oracle.compute(t, 1 << 20, msg).hex() == rec["digest_hex"]
+        two = np.concatenate([np.zeros(256, dtype=np.uint8), msg])   # window 0: 256 zero bytes, window 1: the message
+        assert oracle.compute(t, 256, two)[32:].hex() == rec["digest_hex"]
 
 
 def test_kat(vectors):
