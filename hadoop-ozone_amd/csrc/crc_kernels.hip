@@ -674,9 +674,19 @@ __global__ __launch_bounds__(kThreads) void crc_desc_kernel(const WindowDesc* de
 // Measured and not kept: issuing the loads of a wavefront's NEXT windows before the arithmetic of the current ones
 // (whole windows of 128 B to 2 KiB as one load group, two register buffers taking turns, 114 VGPRs, no spills) was
 // no faster at 128 / 256 B and 5-12 % slower from 512 B to 2 KiB: what these windows lack is not bytes in flight.
-template <int LPW, int MODE, int UNR, int PH>
+//
+// HOLD > 0 (compute): a wavefront keeps its digests in registers and stores them when all its reads are done.  A digest
+// line written while the chip streams the data is pushed out of the L2 by that stream and reaches DRAM as a lone write
+// inside a saturated read stream, which costs its channel a bus turnaround and a row change: 128 MiB of digests (512-byte
+// windows, 16 GiB of data) cost 15 % of the launch, where the same stores issued after the reads cost 2 %
+// (tools/hbm_read_bench.hip, "rolling").  The digests of one pass (valid in the last lane of each lane group) are pulled
+// into one slot group of a collector register by a ds_bpermute; a collector holds LPW passes, a wavefront HOLD collectors
+// per row, i.e. HOLD * LPW passes -- the launcher cuts a larger batch into launches of that many passes (crc_launch), and a
+// wavefront that is nevertheless given more stores the excess as it comes.
+template <int LPW, int MODE, int UNR, int PH, int HOLD = 0>
 __global__ __launch_bounds__(kThreads) void crc_flat_kernel(const CrcLaunch p) {
   __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
+  static_assert(HOLD == 0 || (MODE == kModeCompute && PH == 1), "digests are held by the unphased compute form only");
   constexpr uint32_t kStripe = 16u * LPW;
   constexpr uint32_t kGroup = UNR * kStripe;  // bytes of a window one load group covers
   constexpr int kWinPerRow = 64 / LPW;
@@ -704,6 +714,15 @@ __global__ __launch_bounds__(kThreads) void crc_flat_kernel(const CrcLaunch p) {
   const uint32_t phase = PH > 1 ? (uint32_t)(__builtin_amdgcn_readfirstlane(wave) & (PH - 1)) * (p.bpc / PH) : 0u;
   const uint32_t init0 = phase == 0 ? init : 0u;
   Z4Addr za = z4_addr_init(), zb = z4_addr_init();  // one set per row: the two chains interleave
+  // HOLD: collectors of rows A and B; slot group s (lanes s * kWinPerRow ...) of collector q holds pass q * LPW + s
+  constexpr int kHeld = HOLD ? HOLD : 1;
+  uint32_t keep_a[kHeld], keep_b[kHeld];
+#pragma unroll
+  for (int q = 0; q < kHeld; q++) keep_a[q] = keep_b[q] = 0u;
+  uint32_t cur_a = 0, cur_b = 0;
+  uint32_t pass = 0;  // passes of this wavefront so far (the same in all lanes)
+  const uint32_t pull = (uint32_t)((lane % kWinPerRow) * LPW + (LPW - 1)) * 4u;  // ds_bpermute address: the lane that holds window (lane % kWinPerRow) of a row
+  const uint32_t slot = (uint32_t)(lane / kWinPerRow);                            // the pass (mod LPW) this lane keeps
 
   for (uint64_t w0 = ((uint64_t)blockIdx.x * kWaves + wave) * kWinPerWave; w0 < p.n_windows;
        w0 += (uint64_t)gridDim.x * kWaves * kWinPerWave) {
@@ -854,6 +873,23 @@ __global__ __launch_bounds__(kThreads) void crc_flat_kernel(const CrcLaunch p) {
       y ^= lanes_up(t, i);
     }
 #endif
+    if (HOLD > 0 && pass < (uint32_t)(HOLD * LPW)) {
+      const uint32_t ta = (uint32_t)__builtin_amdgcn_ds_bpermute((int)pull, (int)x);
+      const uint32_t tb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)pull, (int)y);
+      const bool mine = slot == (pass & (LPW - 1));
+      cur_a = mine ? ta : cur_a;
+      cur_b = mine ? tb : cur_b;
+      pass++;
+      if ((pass & (LPW - 1)) == 0) {  // the collector is full (a scalar condition)
+        const uint32_t full = pass / LPW - 1;
+#pragma unroll
+        for (int q = 0; q < kHeld; q++) {
+          keep_a[q] = full == (uint32_t)q ? cur_a : keep_a[q];
+          keep_b[q] = full == (uint32_t)q ? cur_b : keep_b[q];
+        }
+      }
+      continue;
+    }
     if (sl == LPW - 1) {
       if (MODE == kModeCompute) {  // sums is 4-byte aligned in this layout (checked by the launcher)
         uint32_t* out = reinterpret_cast<uint32_t*>(p.sums);
@@ -862,6 +898,28 @@ __global__ __launch_bounds__(kThreads) void crc_flat_kernel(const CrcLaunch p) {
       } else {
         if (ga <= last) judge(p, chunk_a, wi_a, st_a, __builtin_bswap32(~x));
         if (gb <= last) judge(p, chunk_b, wi_b, st_b, __builtin_bswap32(~y));
+      }
+    }
+  }
+  if (HOLD > 0) {  // all reads of this wavefront are done: its digests leave now
+    if ((pass & (LPW - 1)) != 0) {  // a collector that is not full yet
+      const uint32_t part = pass / LPW;
+#pragma unroll
+      for (int q = 0; q < kHeld; q++) {
+        keep_a[q] = part == (uint32_t)q ? cur_a : keep_a[q];
+        keep_b[q] = part == (uint32_t)q ? cur_b : keep_b[q];
+      }
+    }
+    uint32_t* out = reinterpret_cast<uint32_t*>(p.sums);
+    const uint64_t first = ((uint64_t)blockIdx.x * kWaves + wave) * kWinPerWave + (uint32_t)(lane % kWinPerRow);
+    const uint64_t stride = (uint64_t)gridDim.x * kWaves * kWinPerWave;
+#pragma unroll
+    for (int q = 0; q < kHeld; q++) {
+      const uint32_t k = (uint32_t)q * LPW + slot;  // the pass this lane's slot of collector q belongs to
+      if (k < pass) {
+        const uint64_t g = first + (uint64_t)k * stride;
+        if (g <= last) out[g] = __builtin_bswap32(~keep_a[q]);
+        if (g + kWinPerRow <= last) out[g + kWinPerRow] = __builtin_bswap32(~keep_b[q]);
       }
     }
   }
@@ -882,6 +940,22 @@ hipError_t launch_flat(const CrcLaunch& p, int lpw, int unr, int phases, int blo
     case 4000 + 8 * 8 + 1: crc_flat_kernel<8, MODE, 1, 4><<<blocks, kThreads, 0, stream>>>(p); break;
     case 4000 + 16 * 8 + 1: crc_flat_kernel<16, MODE, 1, 4><<<blocks, kThreads, 0, stream>>>(p); break;
     case 4000 + 32 * 8 + 1: crc_flat_kernel<32, MODE, 1, 4><<<blocks, kThreads, 0, stream>>>(p); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// The compute forms that hold their digests until a wavefront's reads are done; kFlatHold collectors per row.
+constexpr int kFlatHold = 8;
+hipError_t launch_flat_hold(const CrcLaunch& p, int lpw, int unr, int blocks, hipStream_t stream) {
+  switch (lpw * 8 + unr) {
+    case 4 * 8 + 1: crc_flat_kernel<4, kModeCompute, 1, 1, kFlatHold><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 4 * 8 + 2: crc_flat_kernel<4, kModeCompute, 2, 1, kFlatHold><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 8 * 8 + 1: crc_flat_kernel<8, kModeCompute, 1, 1, kFlatHold><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 8 * 8 + 2: crc_flat_kernel<8, kModeCompute, 2, 1, kFlatHold><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 16 * 8 + 1: crc_flat_kernel<16, kModeCompute, 1, 1, kFlatHold><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 16 * 8 + 2: crc_flat_kernel<16, kModeCompute, 2, 1, kFlatHold><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 32 * 8 + 1: crc_flat_kernel<32, kModeCompute, 1, 1, kFlatHold><<<blocks, kThreads, 0, stream>>>(p); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -924,6 +998,7 @@ const int g_no_aligned = env_int("OZCS_CRC_NO_ALIGNED");  // 1 = always take the
 const int g_no_flat = env_int("OZCS_CRC_NO_FLAT");        // 1 = never take the gapless-full-windows kernel
 const int g_force_flat = env_int("OZCS_CRC_FLAT");        // lanes * 8 + stripes per load group, e.g. 34 = 4 lanes, 2 stripes
 const int g_force_phases = env_int("OZCS_CRC_PHASES");    // 1 = no wavefront starts inside its windows, 4 = four phases
+const int g_force_hold = env_int("OZCS_CRC_HOLD");        // 1 = digests always held to the end of a wavefront's reads, -1 = never
 
 }  // namespace
 
@@ -1021,6 +1096,32 @@ hipError_t crc_launch(const CrcLaunch& launch, int mode, int group, int num_cus,
       // four phases need the operators of bpc / 2 and bpc / 4 bytes (nibble tables reach 16 KiB) and whole load
       // groups per quarter window
       if (fp == 4 && ((p.bpc & (p.bpc - 1)) != 0 || p.bpc > 32768 || p.bpc < 64u * fl * fu)) fp = 1;
+      // Compute at windows of 4 KiB and less holds its digests in registers until a wavefront's reads are done (measured
+      // on MI355X: verify, which writes none, runs at 6.5 / 7.0 / 7.1 / 7.0 TB/s at 512 B / 1 / 2 / 4 KiB where compute with
+      // its stores in the stream ran at 6.0 / 6.3 / 6.65 / 6.7; from 8 KiB on the two are level).  A wavefront holds
+      // kFlatHold * lanes passes; a larger batch is cut into launches of that many passes over the whole grid.
+      if (mode == kModeCompute && fp == 1 && g_force_hold >= 0 && (p.bpc <= 4096 || g_force_hold > 0) &&
+          p.bpc % (16u * fl * fu) == 0) {
+        const uint64_t per_pass = (uint64_t)num_cus * kWaves * 2 * (64 / fl);  // windows of one pass of a full grid
+        const uint64_t cap = per_pass * (uint64_t)(kFlatHold * fl);
+        const uint64_t launches = (p.n_windows + cap - 1) / cap;
+        uint64_t share = (p.n_windows + launches - 1) / launches;  // equal shares, whole passes
+        share = (share + per_pass - 1) / per_pass * per_pass;
+        hipError_t e = hipSuccess;
+        for (uint64_t off = 0; off < p.n_windows && e == hipSuccess; off += share) {
+          CrcLaunch q = p;  // window g of the gapless layout is data + g * bpc, its digest sums + 4 g
+          q.data = p.data + off * p.bpc;
+          q.sums = p.sums + off * 4;
+          q.n_windows = p.n_windows - off < share ? p.n_windows - off : share;
+          const uint64_t per = (uint64_t)kWaves * 2 * (64 / fl);
+          uint64_t fb = (q.n_windows + per - 1) / per;
+          if (fb > (uint64_t)num_cus) fb = num_cus;
+          e = launch_flat_hold(q, fl, fu, (int)fb, stream);
+          if (e == hipErrorInvalidValue && off == 0) break;  // that (lanes, group) pair is not built in this form
+        }
+        if (e != hipErrorInvalidValue) return e;
+        (void)hipGetLastError();
+      }
       if (p.bpc % (16u * fl * fu) == 0) {
         const uint64_t per = (uint64_t)kWaves * 2 * (64 / fl);
         uint64_t fb = (p.n_windows + per - 1) / per;

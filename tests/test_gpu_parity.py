@@ -994,6 +994,26 @@ def test_default_kernel_selection_four_phase_flat_crc(gpu, t, bpc, gib):
     assert v[c] == wpc - 1 and (np.delete(v, c) == -1).all()
 
 
+
+@pytest.mark.parametrize("bpc,mib", [(512, 320), (128, 640), (4096, 600), (256, 100)])
+def test_compute_small_windows_digests_held_to_the_end_of_a_wavefronts_reads(gpu, bpc, mib):
+    # compute at windows of 4 KiB and less keeps a wavefront's digests in registers and stores them when its reads are
+    # done: several passes per wavefront (more than one collector register), a batch that needs more than one launch
+    # (128 B x 640 MiB), a last pass that is not full, and every digest against the oracle
+    torch, native, L = gpu
+    n = mib * (1 << 20) + 3 * bpc          # a ragged number of windows: the last pass is partial
+    host = oracle.splitmix64(900 + bpc, n)
+    d = torch.from_numpy(host).cuda()
+    for t in (oracle.CRC32, oracle.CRC32C):
+        got = dev_compute(gpu, t, bpc, d, n, 1, n)
+        want = oracle.compute(t, bpc, host)
+        assert len(got) == len(want) == 4 * (n // bpc)
+        if got != want:
+            a, b = np.frombuffer(got, dtype=np.uint32), np.frombuffer(want, dtype=np.uint32)
+            bad = np.nonzero(a != b)[0]
+            raise AssertionError("type %d bpc %d: %d of %d digests differ, first at window %d" % (t, bpc, len(bad), len(a), bad[0]))
+
+
 @pytest.mark.parametrize("t", [oracle.SHA256, oracle.MD5])
 def test_default_kernel_selection_whole_line_digest_loaders(gpu, t):
     # No override: from eight wavefronts per CU on (131,072 windows on 256 CUs) the launcher takes the loaders that

@@ -296,6 +296,10 @@ __global__ __launch_bounds__(1024) void read_flat_rolling(const uint8_t* p, uint
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   acc ^= acc2;
+  if (WORK & 2048) {  // every digest of the wavefront written when its reads are done (as if they had been kept in registers)
+    const uint64_t first = ((uint64_t)blockIdx.x * 16 + wave) * 2 * kPerRow;
+    for (uint64_t j = lane; first + (j / 16) * step < nwin; j += 64) digests[first + (j / 16) * step + (j % 16)] = acc.x + (uint32_t)j;
+  }
   if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = lds[5];
 }
 
@@ -478,6 +482,11 @@ int main(int argc, char** argv) {
     timeit("512 B windows, 8 lanes, LDS lookups + digest stores in bursts of 16 groups, sc1", bytes, [&] { read_flat_store_bursts<16, true><<<256, 1024>>>(d, nw, out, dig); });
     timeit("512 B windows, 8 lanes, LDS lookups + digest stores in bursts of 32 groups", bytes, [&] { read_flat_store_bursts<32, false><<<256, 1024>>>(d, nw, out, dig); });
     timeit("512 B windows, 8 lanes, LDS lookups + digest stores in bursts of 32 groups, sc1", bytes, [&] { read_flat_store_bursts<32, true><<<256, 1024>>>(d, nw, out, dig); });
+    for (int parts : {1, 2, 4, 8, 16}) {
+      char name[128];
+      snprintf(name, sizeof name, "512 B windows, 8 lanes, LDS lookups + all digests stored at the end, %d launches", parts);
+      timeit(name, bytes, [&] { for (int q = 0; q < parts; q++) read_flat_rolling<8, 4, 1, 2049><<<256, 1024>>>(d + (bytes / parts) * q, nw / parts, out, dig + (nw / parts) * q); });
+    }
     ROLL(1, 69, "LDS lookups + digest stores every fourth group, whole lines") ROLL(4, 69, "LDS lookups + digest stores every fourth group, whole lines")
     ROLL(1, 9, "LDS lookups + serial fold") ROLL(2, 9, "LDS lookups + serial fold") ROLL(4, 9, "LDS lookups + serial fold")
     ROLL(1, 13, "LDS lookups + serial fold + digest stores") ROLL(2, 13, "LDS lookups + serial fold + digest stores")
