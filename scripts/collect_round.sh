@@ -16,5 +16,6 @@ python scripts/summarize_pmc.py cfg4 SHA256-1048576-128 sha256_split_windows_ker
 python scripts/summarize_pmc.py md51m MD5-1048576-128 digest_windows_kernel $((2*H + 2*H/MIB*16)) 1 $((2*H/MIB/64*16385))
 python scripts/summarize_pmc.py sha16k SHA256-16384-32 digest_windows_kernel $((H/2 + H/2/16384*32)) 10 $((H/2/16384/64*257))
 python scripts/summarize_pmc.py md516k MD5-16384-32 digest_windows_kernel $((H/2 + H/2/16384*16)) 10 $((H/2/16384/64*257))
-python scripts/summarize_pmc.py flat512 CRC32-512-64 crc_flat_kernel $((H + H/512*4)) 10
+# 512-byte windows: 32 Mi windows a step, 4 Mi windows a launch (8 collectors x 8 passes per wavefront): 8 launches a step
+python scripts/summarize_pmc.py flat512 CRC32-512-64 crc_flat_kernel $((H + H/512*4)) 10 0 8
 python scripts/summarize_pmc.py flat16k CRC32-16384-64 crc_flat_kernel $((H + H/16384*4)) 10

@@ -15,6 +15,7 @@ for seed in ${SEEDS:-101 102 103 104 105 106 107 108}; do
   for l in 4 8 16 32; do run OZCS_CRC_LPW=$l $seed crc; run OZCS_CRC_LPW=$l OZCS_CRC_NO_FLAT=1 $seed crc; done
   for l in 8 16 32; do run OZCS_CRC_LPW=$l OZCS_CRC_PHASES=4 $seed pow2; done
   run OZCS_CRC_LPW=8 OZCS_CRC_NO_ALIGNED=1 $seed crc
+  for h in 1 -1; do run OZCS_CRC_HOLD=$h $seed crc; run OZCS_CRC_HOLD=$h $seed pow2; done
   run OZCS_SHA_SPLIT=0 OZCS_MD5_LINES=0 OZCS_SHA_LINES=0 $seed digests
   run OZCS_SHA_SPLIT=0 OZCS_MD5_LINES=1 OZCS_SHA_LINES=1 $seed digests
   run OZCS_SHA_SPLIT=1 OZCS_MD5_LINES=1 OZCS_SHA_LINES=1 $seed digests

@@ -2,13 +2,16 @@
 """Turns the rocprofv3 output of scripts/profile_config.sh (gpurun_out/prof_<TAG>_*) into an entry of
 profiles/pmc_summary.json and a kernel-stats CSV under profiles/.
 
-    scripts/summarize_pmc.py TAG KEY KERNEL_SUBSTRING ALGORITHMIC_BYTES [WARMUP_LAUNCHES [WAVE_BLOCKS]]
+    scripts/summarize_pmc.py TAG KEY KERNEL_SUBSTRING ALGORITHMIC_BYTES [WARMUP_STEPS [WAVE_BLOCKS [LAUNCHES_PER_STEP]]]
 
 KEY is "<type>-<bpc>-<blocks>" as bench.py looks it up.  HBM bytes per launch = FETCH_SIZE [KiB] x 1024 x 2 +
 WRITE_SIZE [KiB] x 1024: gfx950 tallies a 128-byte read request as 64 bytes in FETCH_SIZE (cross-check:
 TCC_EA0_RDREQ_sum x 128 B).  The entry is stamped with the hash of the kernel sources it was taken from; bench.py
 ignores entries whose stamp differs from the sources of the library it runs.  WAVE_BLOCKS (digests): wavefronts x
-64-byte blocks per window of one launch; SQ_INSTS_VALU divided by it is the vector instructions per block."""
+64-byte blocks per window of one launch; SQ_INSTS_VALU divided by it is the vector instructions per block.
+LAUNCHES_PER_STEP: a step that the launcher cuts into several launches of the same kernel (small-window CRC compute
+holds a wavefront's digests in registers and a launch is as long as those last); counters and times of that many
+consecutive launches are added up, so that every figure of the entry is per step, as bench.py's are."""
 import collections
 import csv
 import glob
@@ -23,17 +26,25 @@ OUT = os.path.join(ROOT, "gpurun_out")
 TAG, KEY, KERNEL, ALG_BYTES = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
 WARMUP = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 WAVE_BLOCKS = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+PER_STEP = int(sys.argv[7]) if len(sys.argv) > 7 else 1
+
+
+def per_step(values):
+    """Sums of PER_STEP consecutive launches (an incomplete last group is dropped)."""
+    return [sum(values[i:i + PER_STEP]) for i in range(0, len(values) - PER_STEP + 1, PER_STEP)]
 
 
 def counters():
     agg = collections.defaultdict(list)
     kernel = None
     for f in sorted(glob.glob(os.path.join(OUT, "prof_%s_pmc_*" % TAG, "**", "*counter_collection.csv"), recursive=True)):
-        for r in csv.DictReader(open(f)):
-            if KERNEL in r["Kernel_Name"]:
-                kernel = r["Kernel_Name"]
-                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    return kernel, {k: {"launches": len(v), "avg": sum(v) / len(v), "min": min(v), "max": max(v)} for k, v in sorted(agg.items())}
+        rows = [r for r in csv.DictReader(open(f)) if KERNEL in r["Kernel_Name"]]
+        rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+        for r in rows:
+            kernel = r["Kernel_Name"]
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    agg = {k: per_step(v) for k, v in agg.items()}
+    return kernel, {k: {"launches": len(v), "avg": sum(v) / len(v), "min": min(v), "max": max(v)} for k, v in sorted(agg.items()) if v}
 
 
 def kernel_times():
@@ -43,12 +54,12 @@ def kernel_times():
     for f in glob.glob(os.path.join(OUT, "prof_%s_trace" % TAG, "**", "*kernel_stats.csv"), recursive=True):
         shutil.copy(f, os.path.join(ROOT, "profiles", "%s_kernel_stats_%s.csv" % (os.environ.get("ROUND", "r03"), TAG)))
         for r in csv.DictReader(open(f)):
-            if KERNEL in r["Name"] and int(r["Calls"]) > calls:   # the variant the run is about: the one launched most
-                avg_ns, calls = float(r["AverageNs"]), int(r["Calls"])
+            if KERNEL in r["Name"] and int(r["Calls"]) > calls * PER_STEP:   # the variant the run is about: the one launched most
+                avg_ns, calls = float(r["AverageNs"]) * PER_STEP, int(r["Calls"]) // PER_STEP
     for f in glob.glob(os.path.join(OUT, "prof_%s_trace" % TAG, "**", "*kernel_trace.csv"), recursive=True):
         rows = [r for r in csv.DictReader(open(f)) if KERNEL in r["Kernel_Name"]]
         rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-        d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows][WARMUP:]
+        d = per_step([int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows])[WARMUP:]
         if d:
             warm = sum(d) / len(d)
     return avg_ns, calls, warm
@@ -63,7 +74,7 @@ def main():
                    "--no-cpu-baseline --no-ceiling ...",
         "source_hash": native.source_hash(),
         "kernel": kernel, "kernel_avg_ns_profiled": avg_ns, "kernel_calls_profiled": calls,
-        "kernel_avg_ns_after_warmup": warm_ns, "warmup_launches_excluded": WARMUP,
+        "kernel_avg_ns_after_warmup": warm_ns, "warmup_launches_excluded": WARMUP, "launches_per_step": PER_STEP,
         "algorithmic_bytes_per_launch": ALG_BYTES, "counters": c,
     }
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:

@@ -575,7 +575,8 @@ def test_cpp_host_mirror_standalone(gpu):
 @pytest.mark.parametrize("env", [{"OZCS_CRC_LPW": "64", "OZCS_CRC_GROUP": g} for g in ("1", "2", "4", "8", "16")] +
                          [{"OZCS_CRC_LPW": l} for l in ("4", "8", "16", "32")] +
                          [{"OZCS_CRC_LPW": "8", "OZCS_CRC_FLAT": "66"}, {"OZCS_CRC_LPW": "4", "OZCS_CRC_FLAT": "34"},
-                          {"OZCS_CRC_LPW": "8", "OZCS_CRC_NO_FLAT": "1"}, {"OZCS_CRC_LPW": "8", "OZCS_CRC_NO_ALIGNED": "1"}],
+                          {"OZCS_CRC_LPW": "8", "OZCS_CRC_NO_FLAT": "1"}, {"OZCS_CRC_LPW": "8", "OZCS_CRC_NO_ALIGNED": "1"},
+                          {"OZCS_CRC_HOLD": "1"}, {"OZCS_CRC_HOLD": "-1"}, {"OZCS_CRC_LPW": "16", "OZCS_CRC_HOLD": "1"}],
                          ids=lambda e: "-".join("%s%s" % (k[9:], v) for k, v in e.items()))
 def test_forced_kernel_variants_random_shapes(gpu, env):
     # the launcher's heuristics normally pick the variant; here each one must be right on ANY shape
