@@ -686,7 +686,7 @@ __global__ __launch_bounds__(kThreads) void crc_desc_kernel(const WindowDesc* de
 template <int LPW, int MODE, int UNR, int PH, int HOLD = 0>
 __global__ __launch_bounds__(kThreads) void crc_flat_kernel(const CrcLaunch p) {
   __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
-  static_assert(HOLD == 0 || (MODE == kModeCompute && PH == 1), "digests are held by the unphased compute form only");
+  static_assert(HOLD == 0 || MODE == kModeCompute, "digests are held by the compute forms only");
   constexpr uint32_t kStripe = 16u * LPW;
   constexpr uint32_t kGroup = UNR * kStripe;  // bytes of a window one load group covers
   constexpr int kWinPerRow = 64 / LPW;
@@ -947,7 +947,12 @@ hipError_t launch_flat(const CrcLaunch& p, int lpw, int unr, int phases, int blo
 
 // The compute forms that hold their digests until a wavefront's reads are done; kFlatHold collectors per row.
 constexpr int kFlatHold = 8;
-hipError_t launch_flat_hold(const CrcLaunch& p, int lpw, int unr, int blocks, hipStream_t stream) {
+hipError_t launch_flat_hold(const CrcLaunch& p, int lpw, int unr, int phases, int blocks, hipStream_t stream) {
+  if (phases == 4) {
+    if (lpw == 8 && unr == 1) crc_flat_kernel<8, kModeCompute, 1, 4, kFlatHold><<<blocks, kThreads, 0, stream>>>(p);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+  }
   switch (lpw * 8 + unr) {
     case 4 * 8 + 1: crc_flat_kernel<4, kModeCompute, 1, 1, kFlatHold><<<blocks, kThreads, 0, stream>>>(p); break;
     case 4 * 8 + 2: crc_flat_kernel<4, kModeCompute, 2, 1, kFlatHold><<<blocks, kThreads, 0, stream>>>(p); break;
@@ -1098,9 +1103,10 @@ hipError_t crc_launch(const CrcLaunch& launch, int mode, int group, int num_cus,
       if (fp == 4 && ((p.bpc & (p.bpc - 1)) != 0 || p.bpc > 32768 || p.bpc < 64u * fl * fu)) fp = 1;
       // Compute at windows of 4 KiB and less holds its digests in registers until a wavefront's reads are done (measured
       // on MI355X: verify, which writes none, runs at 6.5 / 7.0 / 7.1 / 7.0 TB/s at 512 B / 1 / 2 / 4 KiB where compute with
-      // its stores in the stream ran at 6.0 / 6.3 / 6.65 / 6.7; from 8 KiB on the two are level).  A wavefront holds
+      // its stores in the stream ran at 6.0 / 6.3 / 6.65 / 6.7; from 8 KiB on the two are level, but for 16 KiB, where
+      // the phased form reads faster than its neighbours and the stores showed again: 6.92 against 7.01).  A wavefront holds
       // kFlatHold * lanes passes; a larger batch is cut into launches of that many passes over the whole grid.
-      if (mode == kModeCompute && fp == 1 && g_force_hold >= 0 && (p.bpc <= 4096 || g_force_hold > 0) &&
+      if (mode == kModeCompute && g_force_hold >= 0 && (p.bpc <= 4096 || p.bpc == 16384 || g_force_hold > 0) &&
           p.bpc % (16u * fl * fu) == 0) {
         const uint64_t per_pass = (uint64_t)num_cus * kWaves * 2 * (64 / fl);  // windows of one pass of a full grid
         const uint64_t cap = per_pass * (uint64_t)(kFlatHold * fl);
@@ -1116,7 +1122,7 @@ hipError_t crc_launch(const CrcLaunch& launch, int mode, int group, int num_cus,
           const uint64_t per = (uint64_t)kWaves * 2 * (64 / fl);
           uint64_t fb = (q.n_windows + per - 1) / per;
           if (fb > (uint64_t)num_cus) fb = num_cus;
-          e = launch_flat_hold(q, fl, fu, (int)fb, stream);
+          e = launch_flat_hold(q, fl, fu, fp, (int)fb, stream);
           if (e == hipErrorInvalidValue && off == 0) break;  // that (lanes, group) pair is not built in this form
         }
         if (e != hipErrorInvalidValue) return e;
