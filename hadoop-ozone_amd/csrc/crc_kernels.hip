@@ -723,6 +723,61 @@ __global__ __launch_bounds__(kThreads) void crc_flat_kernel(const CrcLaunch p) {
   uint32_t pass = 0;  // passes of this wavefront so far (the same in all lanes)
   const uint32_t pull = (uint32_t)((lane % kWinPerRow) * LPW + (LPW - 1)) * 4u;  // ds_bpermute address: the lane that holds window (lane % kWinPerRow) of a row
   const uint32_t slot = (uint32_t)(lane / kWinPerRow);                            // the pass (mod LPW) this lane keeps
+  // The fold of a window group -- seven LDS round trips that wait for one another -- runs one pass late in the holding
+  // form, between the requests for the next group's first stripes and their first use: it then fills the memory latency
+  // every pass begins with instead of standing behind the pass.  Measured on MI355X with 8 lanes per window: 5.46 -> 5.73
+  // TB/s at 256-byte windows, 6.44 -> 6.59 at 512 B, 6.89 -> 6.96 at 1 KiB; with 4 lanes (128 B) it loses (5.42 -> 5.06)
+  // and with 16 (4 KiB) it changes nothing, so those keep the fold inside the pass.  Only the collectors depend on the
+  // order of the passes, and they see it unchanged.
+  // Verify does the same: the late pass carries its windows' places and stored digests along.
+  constexpr bool kLate = (HOLD > 0 || MODE == kModeVerify) && PH == 1 && LPW == 8;
+  Acc4 late_a = {0, 0, 0, 0}, late_b = {0, 0, 0, 0};
+  bool late = false;
+  struct Place {  // verify: where a pass's two windows (of this lane group) stand and what is stored for them
+    uint64_t chunk_a, wi_a, chunk_b, wi_b;
+    Stored st_a, st_b;
+    bool has_a, has_b;
+  };
+  Place late_at = {0, 0, 0, 0, {0u, false}, {0u, false}, false, false};
+  auto judge_pass = [&](const Place& at, uint32_t x, uint32_t y) {
+    if (sl == LPW - 1) {
+      if (at.has_a) judge(p, at.chunk_a, at.wi_a, at.st_a, __builtin_bswap32(~x));
+      if (at.has_b) judge(p, at.chunk_b, at.wi_b, at.st_b, __builtin_bswap32(~y));
+    }
+  };
+  auto fold = [&](const Acc4& fa, const Acc4& fb, uint32_t& x, uint32_t& y) {
+#ifdef OZCS_TUNE_NOFOLD  // timing-only build: what the loop and the loads cost without the per-window fold; results are wrong on purpose
+    x = fa.a0 ^ fa.a1 ^ fa.a2 ^ fa.a3;
+    y = fb.a0 ^ fb.a1 ^ fb.a2 ^ fb.a3;
+#else
+    x = slot_fold_chain(lds, za, fa);
+    y = slot_fold_chain(lds, zb, fb);
+#pragma unroll
+    for (int i = 0; i < kLevels; i++) {  // as in crc_subwave_kernel
+      const bool taker = (sl & ((2 << i) - 1)) == (2 << i) - 1;
+      const uint32_t below = lanes_up(x, i);
+      const uint32_t t = nib_apply(lds, kOpZ16 + i, taker ? below : y);
+      x ^= t;
+      y ^= lanes_up(t, i);
+    }
+#endif
+  };
+  auto collect = [&](uint32_t x, uint32_t y) {  // files one pass's digests into the collectors (pass < HOLD * LPW)
+    const uint32_t ta = (uint32_t)__builtin_amdgcn_ds_bpermute((int)pull, (int)x);
+    const uint32_t tb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)pull, (int)y);
+    const bool mine = slot == (pass & (LPW - 1));
+    cur_a = mine ? ta : cur_a;
+    cur_b = mine ? tb : cur_b;
+    pass++;
+    if ((pass & (LPW - 1)) == 0) {  // the collector is full (a scalar condition)
+      const uint32_t full = pass / LPW - 1;
+#pragma unroll
+      for (int q = 0; q < kHeld; q++) {
+        keep_a[q] = full == (uint32_t)q ? cur_a : keep_a[q];
+        keep_b[q] = full == (uint32_t)q ? cur_b : keep_b[q];
+      }
+    }
+  };
 
   for (uint64_t w0 = ((uint64_t)blockIdx.x * kWaves + wave) * kWinPerWave; w0 < p.n_windows;
        w0 += (uint64_t)gridDim.x * kWaves * kWinPerWave) {
@@ -758,6 +813,13 @@ __global__ __launch_bounds__(kThreads) void crc_flat_kernel(const CrcLaunch p) {
           na[k] = ld16(ua + k * kStripe);
           nb[k] = ld16(ub + k * kStripe);
         }
+      }
+      if (kLate && late) {  // the previous pass's fold, while this pass's first stripes are on their way
+        uint32_t x, y;
+        fold(late_a, late_b, x, y);
+        if (MODE == kModeVerify) judge_pass(late_at, x, y);
+        else collect(x, y);
+        late = false;
       }
       a = {ca[0].x ^ init, ca[0].y, ca[0].z, ca[0].w};
       b = {cb[0].x ^ init, cb[0].y, cb[0].z, cb[0].w};
@@ -860,34 +922,17 @@ __global__ __launch_bounds__(kThreads) void crc_flat_kernel(const CrcLaunch p) {
 #pragma unroll
       for (int k = 0; k < 8; k++) *va[k] ^= vt[k];
     }
-#ifdef OZCS_TUNE_NOFOLD  // timing-only build: what the loop and the loads cost without the per-window fold; results are wrong on purpose
-    uint32_t x = a.a0 ^ a.a1 ^ a.a2 ^ a.a3, y = b.a0 ^ b.a1 ^ b.a2 ^ b.a3;
-#else
-    uint32_t x = slot_fold_chain(lds, za, a), y = slot_fold_chain(lds, zb, b);
-#pragma unroll
-    for (int i = 0; i < kLevels; i++) {  // as in crc_subwave_kernel
-      const bool taker = (sl & ((2 << i) - 1)) == (2 << i) - 1;
-      const uint32_t below = lanes_up(x, i);
-      const uint32_t t = nib_apply(lds, kOpZ16 + i, taker ? below : y);
-      x ^= t;
-      y ^= lanes_up(t, i);
+    if (kLate && (MODE == kModeVerify || pass < (uint32_t)(HOLD * LPW))) {  // folded during the next pass (or after the last)
+      late_a = a;
+      late_b = b;
+      late = true;
+      if (MODE == kModeVerify) late_at = Place{chunk_a, wi_a, chunk_b, wi_b, st_a, st_b, ga <= last, gb <= last};
+      continue;
     }
-#endif
-    if (HOLD > 0 && pass < (uint32_t)(HOLD * LPW)) {
-      const uint32_t ta = (uint32_t)__builtin_amdgcn_ds_bpermute((int)pull, (int)x);
-      const uint32_t tb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)pull, (int)y);
-      const bool mine = slot == (pass & (LPW - 1));
-      cur_a = mine ? ta : cur_a;
-      cur_b = mine ? tb : cur_b;
-      pass++;
-      if ((pass & (LPW - 1)) == 0) {  // the collector is full (a scalar condition)
-        const uint32_t full = pass / LPW - 1;
-#pragma unroll
-        for (int q = 0; q < kHeld; q++) {
-          keep_a[q] = full == (uint32_t)q ? cur_a : keep_a[q];
-          keep_b[q] = full == (uint32_t)q ? cur_b : keep_b[q];
-        }
-      }
+    uint32_t x, y;
+    fold(a, b, x, y);
+    if (HOLD > 0 && !kLate && pass < (uint32_t)(HOLD * LPW)) {
+      collect(x, y);
       continue;
     }
     if (sl == LPW - 1) {
@@ -901,7 +946,17 @@ __global__ __launch_bounds__(kThreads) void crc_flat_kernel(const CrcLaunch p) {
       }
     }
   }
+  if (MODE == kModeVerify && kLate && late) {
+    uint32_t x, y;
+    fold(late_a, late_b, x, y);
+    judge_pass(late_at, x, y);
+  }
   if (HOLD > 0) {  // all reads of this wavefront are done: its digests leave now
+    if (kLate && late) {
+      uint32_t x, y;
+      fold(late_a, late_b, x, y);
+      collect(x, y);
+    }
     if ((pass & (LPW - 1)) != 0) {  // a collector that is not full yet
       const uint32_t part = pass / LPW;
 #pragma unroll
