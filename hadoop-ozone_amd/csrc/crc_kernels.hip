@@ -1090,6 +1090,10 @@ int crc_choose_lpw(uint64_t n_windows, uint32_t bpc, int num_cus) {
   if (g_force_lpw == 64) return 0;
   if (bpc > 262144) return 0;
   const uint64_t waves = (uint64_t)num_cus * kWaves;
+  // 256 KiB windows in plenty: the wavefront-per-window kernel (eight wavefronts per window) reads them at 7.10-7.14 TB/s
+  // where 8 lanes per window reach 6.92 (65,536 windows, twenty launches after ten); at 32,768 windows it is level with the
+  // 16 lanes taken before (6.96 against 6.91), at 16,384 behind the 32 lanes taken there (6.63 against 6.75)
+  if (bpc == 262144 && n_windows >= 8 * waves) return 0;
   int want = n_windows >= waves * 16 ? 8 : n_windows >= waves * 8 ? 16 : n_windows >= waves * 4 ? 32 : 64;
   // measured twice over: 16 lanes beat 8 at 4 KiB (6.53 against 6.41 TB/s) and 8 KiB windows (6.67 against
   // 6.33), and nowhere else
