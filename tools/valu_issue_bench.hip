@@ -2,6 +2,9 @@
 // ones, and the instruction kinds SHA-256 / MD5 are made of.  One wavefront per launch; cycles from s_memtime.
 //   hipcc -O3 --offload-arch=gfx950 tools/valu_issue_bench.hip -o tools/valu_issue_bench && tools/valu_issue_bench
 #include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 #include <stdint.h>
 #include <stdio.h>
 
@@ -48,18 +51,18 @@ template <int KIND>
 void run(const char* name, int per_iter, uint32_t* out, uint64_t* cyc, int waves) {
   const int REP = 20000;
   hipEvent_t e0, e1;
-  hipEventCreate(&e0);
-  hipEventCreate(&e1);
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
   float ms = 0;
   for (int rep = 0; rep < 3; rep++) {
-    hipEventRecord(e0, 0);
+    CK(hipEventRecord(e0, 0));
     hipLaunchKernelGGL(bench<KIND>, dim3(1), dim3(64 * waves), 0, 0, out, cyc, 12345u + rep, REP);
-    hipEventRecord(e1, 0);
-    hipDeviceSynchronize();
-    hipEventElapsedTime(&ms, e0, e1);
+    CK(hipEventRecord(e1, 0));
+    CK(hipDeviceSynchronize());
+    CK(hipEventElapsedTime(&ms, e0, e1));
   }
   uint64_t c = 0;
-  hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+  CK(hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost));
   const double n = (double)REP * UNROLL * per_iter;
   printf("%-44s waves/WG=%d  %.3f s_memtime ticks, %.3f ns per instruction\n", name, waves, (double)c / n, ms * 1e6 / n);
 }
@@ -67,8 +70,8 @@ void run(const char* name, int per_iter, uint32_t* out, uint64_t* cyc, int waves
 int main() {
   uint32_t* out;
   uint64_t* cyc;
-  hipMalloc(&out, 4096 * 4);
-  hipMalloc(&cyc, 8);
+  CK(hipMalloc(&out, 4096 * 4));
+  CK(hipMalloc(&cyc, 8));
   for (int waves : {1, 4, 8}) {
     run<0>("dependent v_add_u32", 4, out, cyc, waves);
     run<1>("4 independent v_add_u32 (literal)", 4, out, cyc, waves);
