@@ -48,21 +48,32 @@ constexpr int kThreads = 1024;
 constexpr int kWaves = kThreads / 64;
 constexpr uint32_t kWaveBytes = 2048;  // bytes of a stripe one wavefront covers: two 1 KiB rows
 
-// LDS layout in bytes
+// LDS layout in bytes, crc_windows_kernel
 constexpr uint32_t kMainBytes = 4u * 256u * 32u * 4u;          // 128 KiB: 4 byte tables x 32 copies
 constexpr int kNibOps = 14;                                    // operators 0..13 of kOpBytes
 constexpr uint32_t kNibOpBytes = 8u * 16u * 4u;                // 512 B per operator
-// byte tables of the "advance 4 bytes" operator (entry b of table j at kZ4Off + j*1024 + b*4): the small-window
-// kernels merge the four accumulators of a unit with it.  The area starts on a 64 KiB boundary so that a lookup
-// address is the area's upper half-word over a 16-bit index, which one sub-dword shift writes (z4_step).
-constexpr uint32_t kZ4Off = kMainBytes;
-constexpr uint32_t kZ4Bytes = 4u * 256u * 4u;
-static_assert((kZ4Off & 0xffffu) == 0, "z4_step keeps the area's address in the upper half of its address registers");
-constexpr uint32_t kNibOff = kZ4Off + kZ4Bytes;
+constexpr uint32_t kNibOff = kMainBytes;
 static_assert((kNibOff & 0xffu) == 0, "nib_apply takes bytes 1..2 of the table area's address");
 constexpr uint32_t kPartOff = kNibOff + kNibOps * kNibOpBytes;  // 2 x 16 partial registers
 constexpr uint32_t kLdsBytes = kPartOff + 2u * kWaves * 4u;
 static_assert(kLdsBytes <= 160u * 1024u, "one workgroup's tables must fit the CU's 160 KiB of LDS");
+
+// LDS layout of the kernels with several lanes per window (crc_subwave_kernel, crc_desc_kernel, crc_flat_kernel).  Two sets
+// of four byte tables, each in 16 copies: the stripe operator and the "advance 4 bytes" operator that merges the four
+// accumulators of a unit at the end of every window.  Entry b of table t, copy r, stands at b * 256 + t * 64 + r * 4, so
+// table t occupies banks 16 * (t & 1) + r.  Sixteen copies are enough for conflict-free lookups because the four lookups
+// of an accumulator are XORed and their order is therefore free: lanes 0-15 of each half of the wavefront look up
+// (table 0, byte 0) while lanes 16-31 look up (table 1, byte 1), and the next instruction has them the other way round;
+// likewise tables 2 and 3 (SmallLanes).  With one copy of the second set, as it was at first, random bytes met about
+// 3.5 deep in a bank and a third of the LDS cycles at 512-byte windows were conflict cycles; with 16 copies there are
+// none (MI355X, 256-byte windows: 5.63 -> 6.15 TB/s; 512 B: 6.48 -> 6.61).
+constexpr uint32_t kSmallSetBytes = 4u * 256u * 16u * 4u;  // 64 KiB
+constexpr uint32_t kSmallZ4Off = kSmallSetBytes;
+static_assert((kSmallZ4Off & 0xffffu) == 0, "the second set's offset is byte 2 of a lane's address constant");
+constexpr uint32_t kSmallNibOff = kSmallZ4Off + kSmallSetBytes;
+static_assert((kSmallNibOff & 0xffu) == 0, "nib_apply takes bytes 1..2 of the table area's address");
+constexpr uint32_t kSmallLdsBytes = kSmallNibOff + kNibOps * kNibOpBytes;
+static_assert(kSmallLdsBytes <= 160u * 1024u, "one workgroup's tables must fit the CU's 160 KiB of LDS");
 
 __device__ __forceinline__ uint32_t lds_u32(const char* base, uint32_t off) {
   return *reinterpret_cast<const uint32_t*>(base + off);
@@ -77,6 +88,7 @@ __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
 // Index extraction: the eight nibbles, times four, are masked into the bytes of two registers and every
 // LDS address is then ONE v_perm_b32 (byte 0 <- that byte, bytes 1..2 <- the table area's base); the
 // operator's and the nibble's offsets ride in the instruction's immediate offset field.
+template <uint32_t kArea = kNibOff>
 __device__ __forceinline__ uint32_t nib_apply(const char* lds, int op, uint32_t x) {
   const uint32_t m0 = (x << 2) & 0x3c3c3c3cu;  // nibbles 0, 2, 4, 6
   const uint32_t m1 = (x >> 2) & 0x3c3c3c3cu;  // nibbles 1, 3, 5, 7
@@ -84,8 +96,8 @@ __device__ __forceinline__ uint32_t nib_apply(const char* lds, int op, uint32_t 
   uint32_t t[8];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    t[2 * k] = lds_u32(lds, __builtin_amdgcn_perm(m0, kNibOff, 0x0c020104u + k) + (off + (2 * k) * 64u));
-    t[2 * k + 1] = lds_u32(lds, __builtin_amdgcn_perm(m1, kNibOff, 0x0c020104u + k) + (off + (2 * k + 1) * 64u));
+    t[2 * k] = lds_u32(lds, __builtin_amdgcn_perm(m0, kArea, 0x0c020104u + k) + (off + (2 * k) * 64u));
+    t[2 * k + 1] = lds_u32(lds, __builtin_amdgcn_perm(m1, kArea, 0x0c020104u + k) + (off + (2 * k + 1) * 64u));
   }
   return xor3(xor3(t[0], t[1], t[2]), xor3(t[3], t[4], t[5]), t[6] ^ t[7]);
 }
@@ -157,6 +169,53 @@ __device__ __forceinline__ void absorb(const char* lds, uint32_t lb01, uint32_t 
   a.a2 = gather4(lds, r2, d.z);
   a.a3 = gather4(lds, r3, d.w);
 }
+
+// Lane constants and lookups of the 16-copy layout (kSmallSetBytes).  An address is still ONE v_perm_b32 -- byte 0 <- the
+// lane's constant (table and copy), byte 1 <- the selected byte of x, byte 2 <- the set -- but which byte of x a lane
+// selects in which instruction is now the lane's own, so the selector is a register too.
+struct SmallLanes {
+  uint32_t ca, cb;                  // table and copy, stripe set: first and second instruction of a pair
+  uint32_t caz, cbz;                // the same in the "advance 4 bytes" set
+  uint32_t sa01, sb01, sa23, sb23;  // v_perm selectors: bytes 0/1 and 2/3 of x, in the lane's order
+  __device__ __forceinline__ explicit SmallLanes(int lane) {
+    const uint32_t r4 = (uint32_t)(lane & 15) * 4u;
+    const bool hi = (lane & 16) != 0;
+    ca = r4 + (hi ? 64u : 0u);  // first instruction: lanes 0-15 the even table (banks 0-15), lanes 16-31 the odd one (16-31)
+    cb = r4 + (hi ? 0u : 64u);  // second instruction: the other way round
+    caz = ca + kSmallZ4Off;
+    cbz = cb + kSmallZ4Off;
+    sa01 = hi ? 0x0c020500u : 0x0c020400u;
+    sb01 = hi ? 0x0c020400u : 0x0c020500u;
+    sa23 = hi ? 0x0c020700u : 0x0c020600u;
+    sb23 = hi ? 0x0c020600u : 0x0c020700u;
+  }
+  // x * (the set's operator) ^ d
+  __device__ __forceinline__ uint32_t apply(const char* lds, uint32_t a_, uint32_t b_, uint32_t x, uint32_t d) const {
+    const uint32_t t0 = lds_u32(lds, __builtin_amdgcn_perm(x, a_, sa01));
+    const uint32_t t1 = lds_u32(lds, __builtin_amdgcn_perm(x, b_, sb01));
+    const uint32_t t2 = lds_u32(lds, __builtin_amdgcn_perm(x, a_, sa23) + 128u);
+    const uint32_t t3 = lds_u32(lds, __builtin_amdgcn_perm(x, b_, sb23) + 128u);
+    return xor3(xor3(t0, t1, t2), t3, d);
+  }
+  // one stripe step for the four accumulators of a 16-byte unit (sixteen independent lookups)
+  __device__ __forceinline__ void absorb(const char* lds, Acc4& a, const uint4 d) const {
+    const uint32_t n0 = apply(lds, ca, cb, a.a0, d.x), n1 = apply(lds, ca, cb, a.a1, d.y),
+                   n2 = apply(lds, ca, cb, a.a2, d.z), n3 = apply(lds, ca, cb, a.a3, d.w);
+    a = {n0, n1, n2, n3};
+  }
+  // The four accumulators of a unit -> the register after the unit, as a Horner chain in z = x^32:
+  // (((a0 z + a1) z + a2) z + a3) z; the chains of the two rows a wavefront holds interleave.
+  __device__ __forceinline__ void merge_units(const char* lds, const Acc4& a, const Acc4& b, uint32_t& x, uint32_t& y) const {
+    x = apply(lds, caz, cbz, a.a0, a.a1);
+    y = apply(lds, caz, cbz, b.a0, b.a1);
+    x = apply(lds, caz, cbz, x, a.a2);
+    y = apply(lds, caz, cbz, y, b.a2);
+    x = apply(lds, caz, cbz, x, a.a3);
+    y = apply(lds, caz, cbz, y, b.a3);
+    x = apply(lds, caz, cbz, x, 0u);
+    y = apply(lds, caz, cbz, y, 0u);
+  }
+};
 
 // 128-bit load through the global (not flat) address space: flat loads would tie the LDS and the
 // memory wait counters together.
@@ -236,18 +295,39 @@ __device__ __forceinline__ void build_tables(char* lds, const PolyBasis& pb, int
   const uint4 v4 = make_uint4(v, v, v, v);
 #pragma unroll
   for (int r = 0; r < 8; r++) dst[r] = v4;
-  {
-    uint32_t z = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) z ^= ((b >> i) & 1) ? pb.op[kOpZ4].v[8 * j + i] : 0u;
-    *reinterpret_cast<uint32_t*>(lds + kZ4Off + (j * 256 + b) * 4) = z;
-  }
   for (int e = tid; e < kNibOps * 128; e += kThreads) {
     const int op = e >> 7, q = (e >> 4) & 7, nv = e & 15;
     uint32_t w = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) w ^= ((nv >> i) & 1) ? pb.op[op].v[4 * q + i] : 0u;
     *reinterpret_cast<uint32_t*>(lds + kNibOff + e * 4) = w;
+  }
+}
+
+// The tables of the 16-copy layout: the byte tables of operator `main_op` and of "advance 4 bytes", and the nibble
+// tables of operators 0..kNibOps-1.  All kThreads threads take part.
+__device__ __forceinline__ void build_small_tables(char* lds, const PolyBasis& pb, int main_op, int tid) {
+  const int j = tid >> 8, b = tid & 255;  // byte table j, entry b
+  uint32_t v = 0, z = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    v ^= ((b >> i) & 1) ? pb.op[main_op].v[8 * j + i] : 0u;
+    z ^= ((b >> i) & 1) ? pb.op[kOpZ4].v[8 * j + i] : 0u;
+  }
+  uint4* dv = reinterpret_cast<uint4*>(lds + b * 256 + j * 64);
+  uint4* dz = reinterpret_cast<uint4*>(lds + kSmallZ4Off + b * 256 + j * 64);
+  const uint4 v4 = make_uint4(v, v, v, v), z4 = make_uint4(z, z, z, z);
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    dv[r] = v4;
+    dz[r] = z4;
+  }
+  for (int e = tid; e < kNibOps * 128; e += kThreads) {
+    const int op = e >> 7, q = (e >> 4) & 7, nv = e & 15;
+    uint32_t w = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) w ^= ((nv >> i) & 1) ? pb.op[op].v[4 * q + i] : 0u;
+    *reinterpret_cast<uint32_t*>(lds + kSmallNibOff + e * 4) = w;
   }
 }
 
@@ -312,44 +392,6 @@ __device__ __forceinline__ uint32_t finish_window(uint32_t state, bool vec, uint
 __device__ __forceinline__ uint32_t slot_fold(const char* lds, const Acc4& a) {
   return nib_apply(lds, kOpZ16, a.a0) ^ nib_apply(lds, kOpZ12, a.a1) ^ nib_apply(lds, kOpZ8, a.a2) ^
          nib_apply(lds, kOpZ4, a.a3);
-}
-
-// The four LDS addresses one z4_step looks up, kept in registers whose upper half-word holds the table area's
-// address for good: every step rewrites only the lower half-word.
-struct Z4Addr {
-  uint32_t o0, o1, o2, o3;
-};
-__device__ __forceinline__ Z4Addr z4_addr_init() { return Z4Addr{kZ4Off, kZ4Off, kZ4Off, kZ4Off}; }
-
-// x * x^32 mod P ^ nxt through the byte tables of the 4-byte operator: four lookups and six vector instructions
-// against eight lookups and some twenty for a nibble-table operator.  Each address is ONE instruction: a
-// sub-dword shift takes byte k of x, times four, into the lower half-word of the address register and leaves
-// the upper half-word (the area's address) alone; the table's offset rides in the load's immediate.  One copy of
-// the tables: random bytes meet in a bank about 3.5 deep, which the saved instructions outweigh for windows of a
-// few KiB and less.
-__device__ __forceinline__ uint32_t z4_step(const char* lds, Z4Addr& ad, uint32_t x, uint32_t nxt) {
-  const uint32_t two = 2u;
-  asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_0"
-      : "+v"(ad.o0) : "v"(two), "v"(x));
-  asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_1"
-      : "+v"(ad.o1) : "v"(two), "v"(x));
-  asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_2"
-      : "+v"(ad.o2) : "v"(two), "v"(x));
-  asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_3"
-      : "+v"(ad.o3) : "v"(two), "v"(x));
-  const uint32_t t0 = lds_u32(lds, ad.o0), t1 = lds_u32(lds, ad.o1 + 1024u), t2 = lds_u32(lds, ad.o2 + 2048u),
-                 t3 = lds_u32(lds, ad.o3 + 3072u);
-  return xor3(xor3(t0, t1, t2), t3, nxt);
-}
-// slot_fold as a Horner chain over the unit's four accumulators: (((a0 z + a1) z + a2) z + a3) z, z = x^32.
-__device__ __forceinline__ uint32_t slot_fold_chain(const char* lds, Z4Addr& ad, const Acc4& a) {
-#ifdef OZCS_SLOT_NIBBLE  // A/B build: the nibble-table form
-  return slot_fold(lds, a);
-#endif
-  uint32_t x = z4_step(lds, ad, a.a0, a.a1);
-  x = z4_step(lds, ad, x, a.a2);
-  x = z4_step(lds, ad, x, a.a3);
-  return z4_step(lds, ad, x, 0u);
 }
 
 // Folds the accumulators of a wavefront's two rows.  The result, valid in lane 63, is the register a
@@ -515,7 +557,7 @@ __device__ __forceinline__ Win window_of(const CrcLaunch& p, uint64_t g) {
 // The registers of the two windows a lane group works on (rows A and B of the wavefront), valid in the last
 // lane of each group.  All 64 lanes call together.
 template <int LPW, bool AL>
-__device__ __forceinline__ void subwave_pair(const char* lds, uint32_t lb01, uint32_t lb23, int sl, const Win& wa,
+__device__ __forceinline__ void subwave_pair(const char* lds, const SmallLanes& ln, int sl, const Win& wa,
                                              const Win& wb, uint32_t& x, uint32_t& y) {
   constexpr uint32_t kStripe = 16u * LPW;
   constexpr int kLevels = LPW == 4 ? 2 : LPW == 8 ? 3 : LPW == 16 ? 4 : 5;
@@ -535,21 +577,19 @@ __device__ __forceinline__ void subwave_pair(const char* lds, uint32_t lb01, uin
     ub += kStripe;
     if (j + 1 < wa.nst) na = ld16(ua);
     if (j + 1 < wb.nst) nb = ld16(ub);
-    if (j < wa.nst) absorb(lds, lb01, lb23, a, ca);
-    if (j < wb.nst) absorb(lds, lb01, lb23, b, cb);
+    if (j < wa.nst) ln.absorb(lds, a, ca);
+    if (j < wb.nst) ln.absorb(lds, b, cb);
   }
   // Fold.  Only the last lane of a group needs its window's register, so level i has work for the lanes
   // whose low i+1 bits are all ones (they take in the lane 2^i below).  That leaves the lanes below idle:
   // they advance row B's values in the same instruction stream, and the result moves up by one DPP shift.
   // Lanes outside that pattern end up with values nobody reads.
-  Z4Addr za = z4_addr_init(), zb = z4_addr_init();  // one set per row: the two chains interleave
-  x = slot_fold_chain(lds, za, a);
-  y = slot_fold_chain(lds, zb, b);
+  ln.merge_units(lds, a, b, x, y);
 #pragma unroll
   for (int i = 0; i < kLevels; i++) {
     const bool taker = (sl & ((2 << i) - 1)) == (2 << i) - 1;
     const uint32_t below = lanes_up(x, i);  // outside the select: every lane must execute the shift
-    const uint32_t t = nib_apply(lds, kOpZ16 + i, taker ? below : y);
+    const uint32_t t = nib_apply<kSmallNibOff>(lds, kOpZ16 + i, taker ? below : y);
     x ^= t;
     y ^= lanes_up(t, i);
   }
@@ -557,7 +597,7 @@ __device__ __forceinline__ void subwave_pair(const char* lds, uint32_t lb01, uin
 
 template <int LPW, int MODE, bool AL>
 __global__ __launch_bounds__(kThreads) void crc_subwave_kernel(const CrcLaunch p) {
-  __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
+  __shared__ __attribute__((aligned(16))) char lds[kSmallLdsBytes];
   constexpr uint32_t kStripe = 16u * LPW;
   constexpr int kWinPerRow = 64 / LPW;
   constexpr int kWinPerWave = 2 * kWinPerRow;
@@ -567,11 +607,10 @@ __global__ __launch_bounds__(kThreads) void crc_subwave_kernel(const CrcLaunch p
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  build_tables(lds, c_basis[p.poly_idx], kMainOp, tid);
+  build_small_tables(lds, c_basis[p.poly_idx], kMainOp, tid);
   __syncthreads();
 
-  const uint32_t lb01 = (uint32_t)(lane & 31) * 4u;
-  const uint32_t lb23 = lb01 + 65536u;
+  const SmallLanes ln(lane);
   const int sl = lane & (LPW - 1);  // lane inside its window's group
   const int grp = lane / LPW;
   const uint32_t poly = p.poly_idx ? kPolyCrc32c : kPolyCrc32;
@@ -581,7 +620,7 @@ __global__ __launch_bounds__(kThreads) void crc_subwave_kernel(const CrcLaunch p
     const uint64_t ga = w0 + grp, gb = w0 + kWinPerRow + grp;
     const Win wa = window_of<kStripe>(p, ga), wb = window_of<kStripe>(p, gb);
     uint32_t x, y;
-    subwave_pair<LPW, AL>(lds, lb01, lb23, sl, wa, wb, x, y);
+    subwave_pair<LPW, AL>(lds, ln, sl, wa, wb, x, y);
     if (sl == LPW - 1) {  // the last lane of a group holds its window's register
       if (wa.valid) emit<MODE>(p, ga, wa.chunk, wa.wi, finish_window(x, wa.vec, wa.s, wa.e16, wa.e, poly));
       if (wb.valid) emit<MODE>(p, gb, wb.chunk, wb.wi, finish_window(y, wb.vec, wb.s, wb.e16, wb.e, poly));
@@ -616,7 +655,7 @@ __device__ __forceinline__ void store_be(uint8_t* out, uint32_t be) {
 
 template <int LPW>
 __global__ __launch_bounds__(kThreads) void crc_desc_kernel(const WindowDesc* desc, uint32_t n, int poly_idx) {
-  __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
+  __shared__ __attribute__((aligned(16))) char lds[kSmallLdsBytes];
   constexpr uint32_t kStripe = 16u * LPW;
   constexpr int kWinPerRow = 64 / LPW;
   constexpr int kWinPerWave = 2 * kWinPerRow;
@@ -626,11 +665,10 @@ __global__ __launch_bounds__(kThreads) void crc_desc_kernel(const WindowDesc* de
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  build_tables(lds, c_basis[poly_idx], kMainOp, tid);
+  build_small_tables(lds, c_basis[poly_idx], kMainOp, tid);
   __syncthreads();
 
-  const uint32_t lb01 = (uint32_t)(lane & 31) * 4u;
-  const uint32_t lb23 = lb01 + 65536u;
+  const SmallLanes ln(lane);
   const int sl = lane & (LPW - 1);
   const int grp = lane / LPW;
   const uint32_t poly = poly_idx ? kPolyCrc32c : kPolyCrc32;
@@ -640,7 +678,7 @@ __global__ __launch_bounds__(kThreads) void crc_desc_kernel(const WindowDesc* de
     const uint64_t ga = w0 + grp, gb = w0 + kWinPerRow + grp;
     const Win wa = window_of_desc<kStripe>(desc, n, ga), wb = window_of_desc<kStripe>(desc, n, gb);
     uint32_t x, y;
-    subwave_pair<LPW, false>(lds, lb01, lb23, sl, wa, wb, x, y);
+    subwave_pair<LPW, false>(lds, ln, sl, wa, wb, x, y);
     if (sl == LPW - 1) {
       if (wa.valid) store_be(desc[ga].out, finish_window(x, wa.vec, wa.s, wa.e16, wa.e, poly));
       if (wb.valid) store_be(desc[gb].out, finish_window(y, wb.vec, wb.s, wb.e16, wb.e, poly));
@@ -685,7 +723,7 @@ __global__ __launch_bounds__(kThreads) void crc_desc_kernel(const WindowDesc* de
 // wavefront that is nevertheless given more stores the excess as it comes.
 template <int LPW, int MODE, int UNR, int PH, int HOLD = 0>
 __global__ __launch_bounds__(kThreads) void crc_flat_kernel(const CrcLaunch p) {
-  __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
+  __shared__ __attribute__((aligned(16))) char lds[kSmallLdsBytes];
   static_assert(HOLD == 0 || MODE == kModeCompute, "digests are held by the compute forms only");
   constexpr uint32_t kStripe = 16u * LPW;
   constexpr uint32_t kGroup = UNR * kStripe;  // bytes of a window one load group covers
@@ -697,11 +735,10 @@ __global__ __launch_bounds__(kThreads) void crc_flat_kernel(const CrcLaunch p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  build_tables(lds, c_basis[p.poly_idx], kMainOp, tid);
+  build_small_tables(lds, c_basis[p.poly_idx], kMainOp, tid);
   __syncthreads();
 
-  const uint32_t lb01 = (uint32_t)(lane & 31) * 4u;
-  const uint32_t lb23 = lb01 + 65536u;
+  const SmallLanes ln(lane);
   const int sl = lane & (LPW - 1);
   const int grp = lane / LPW;
   const uint32_t init = sl == 0 ? 0xFFFFFFFFu : 0u;  // the window's first four bytes are lane 0's first dword
@@ -713,7 +750,6 @@ __global__ __launch_bounds__(kThreads) void crc_flat_kernel(const CrcLaunch p) {
   // whole loop control below)
   const uint32_t phase = PH > 1 ? (uint32_t)(__builtin_amdgcn_readfirstlane(wave) & (PH - 1)) * (p.bpc / PH) : 0u;
   const uint32_t init0 = phase == 0 ? init : 0u;
-  Z4Addr za = z4_addr_init(), zb = z4_addr_init();  // one set per row: the two chains interleave
   // HOLD: collectors of rows A and B; slot group s (lanes s * kWinPerRow ...) of collector q holds pass q * LPW + s
   constexpr int kHeld = HOLD ? HOLD : 1;
   uint32_t keep_a[kHeld], keep_b[kHeld];
@@ -750,13 +786,12 @@ __global__ __launch_bounds__(kThreads) void crc_flat_kernel(const CrcLaunch p) {
     x = fa.a0 ^ fa.a1 ^ fa.a2 ^ fa.a3;
     y = fb.a0 ^ fb.a1 ^ fb.a2 ^ fb.a3;
 #else
-    x = slot_fold_chain(lds, za, fa);
-    y = slot_fold_chain(lds, zb, fb);
+    ln.merge_units(lds, fa, fb, x, y);
 #pragma unroll
     for (int i = 0; i < kLevels; i++) {  // as in crc_subwave_kernel
       const bool taker = (sl & ((2 << i) - 1)) == (2 << i) - 1;
       const uint32_t below = lanes_up(x, i);
-      const uint32_t t = nib_apply(lds, kOpZ16 + i, taker ? below : y);
+      const uint32_t t = nib_apply<kSmallNibOff>(lds, kOpZ16 + i, taker ? below : y);
       x ^= t;
       y ^= lanes_up(t, i);
     }
@@ -825,8 +860,8 @@ __global__ __launch_bounds__(kThreads) void crc_flat_kernel(const CrcLaunch p) {
       b = {cb[0].x ^ init, cb[0].y, cb[0].z, cb[0].w};
 #pragma unroll
       for (int k = 1; k < UNR; k++) {
-        absorb(lds, lb01, lb23, a, ca[k]);
-        absorb(lds, lb01, lb23, b, cb[k]);
+        ln.absorb(lds, a, ca[k]);
+        ln.absorb(lds, b, cb[k]);
       }
       for (uint32_t done = kGroup; done < p.bpc; done += kGroup) {
 #pragma unroll
@@ -845,8 +880,8 @@ __global__ __launch_bounds__(kThreads) void crc_flat_kernel(const CrcLaunch p) {
         }
 #pragma unroll
         for (int k = 0; k < UNR; k++) {
-          absorb(lds, lb01, lb23, a, ca[k]);
-          absorb(lds, lb01, lb23, b, cb[k]);
+          ln.absorb(lds, a, ca[k]);
+          ln.absorb(lds, b, cb[k]);
         }
       }
     } else {
@@ -867,14 +902,14 @@ __global__ __launch_bounds__(kThreads) void crc_flat_kernel(const CrcLaunch p) {
           b = {db[0].x ^ init, db[0].y, db[0].z, db[0].w};
 #pragma unroll
           for (int k = 1; k < UNR; k++) {
-            absorb(lds, lb01, lb23, a, da[k]);
-            absorb(lds, lb01, lb23, b, db[k]);
+            ln.absorb(lds, a, da[k]);
+            ln.absorb(lds, b, db[k]);
           }
         } else {
 #pragma unroll
           for (int k = 0; k < UNR; k++) {
-            absorb(lds, lb01, lb23, a, da[k]);
-            absorb(lds, lb01, lb23, b, db[k]);
+            ln.absorb(lds, a, da[k]);
+            ln.absorb(lds, b, db[k]);
           }
         }
       };
@@ -886,8 +921,8 @@ __global__ __launch_bounds__(kThreads) void crc_flat_kernel(const CrcLaunch p) {
       b = {cb[0].x ^ init0, cb[0].y, cb[0].z, cb[0].w};
 #pragma unroll
       for (int k = 1; k < UNR; k++) {
-        absorb(lds, lb01, lb23, a, ca[k]);
-        absorb(lds, lb01, lb23, b, cb[k]);
+        ln.absorb(lds, a, ca[k]);
+        ln.absorb(lds, b, cb[k]);
       }
       for (uint32_t done = kGroup; done < p.bpc; done += 2 * kGroup) {  // an odd number of groups is left
         const bool more = done + kGroup < p.bpc;
@@ -906,7 +941,7 @@ __global__ __launch_bounds__(kThreads) void crc_flat_kernel(const CrcLaunch p) {
     if (PH > 1 && phase != 0) {
       // window = head | tail: the head's accumulators advance through the tail's bpc - phase bytes (one or two
       // power-of-two operators: PH = 4 gives tails of 3/4, 1/2 and 1/4 of a window) and meet the tail's
-      const uint32_t half = kNibOff + (uint32_t)(__builtin_ctz(p.bpc) - 2) * kNibOpBytes;  // operator of bpc / 2 bytes
+      const uint32_t half = kSmallNibOff + (uint32_t)(__builtin_ctz(p.bpc) - 2) * kNibOpBytes;  // operator of bpc / 2 bytes
       const uint32_t quarter = half - kNibOpBytes;
       const uint32_t tail = p.bpc - phase;
       uint32_t* va[8] = {&a.a0, &a.a1, &a.a2, &a.a3, &b.a0, &b.a1, &b.a2, &b.a3};

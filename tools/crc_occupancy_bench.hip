@@ -44,11 +44,11 @@ __constant__ PolyBasis c_basis = make_poly_basis(kPolyCrc32);
 constexpr int kNibOps = 14;
 constexpr uint32_t kNibOpBytes = 8u * 16u * 4u;
 
-template <int COPIES>
+template <int COPIES, int ZC>
 struct Lay {
   static constexpr uint32_t kMain = 4u * 256u * COPIES * 4u;  // 128 KiB or 64 KiB: a multiple of 64 KiB either way
   static constexpr uint32_t kZ4 = kMain;
-  static constexpr uint32_t kNib = kZ4 + 4096u;
+  static constexpr uint32_t kNib = kZ4 + 4096u * ZC;  // the "advance 4 bytes" byte tables: one copy, or 16 laid out like the main tables
   static constexpr uint32_t kBytes = kNib + kNibOps * kNibOpBytes;
 };
 
@@ -126,6 +126,14 @@ struct LaneC<16> {  // entry b of table t, copy r at b * 256 + t * 64 + r * 4: t
     const uint32_t t3 = lds_u32(lds, __builtin_amdgcn_perm(x, cb, sb23) + 128u);
     return xor3(xor3(t0, t1, t2), t3, d);
   }
+  // the same lookups in a second table set 64 KiB further on (caz = ca + 65536, cbz = cb + 65536: byte 2 of the constant)
+  __device__ __forceinline__ uint32_t gather_at(const char* lds, uint32_t caz, uint32_t cbz, uint32_t x, uint32_t d) const {
+    const uint32_t t0 = lds_u32(lds, __builtin_amdgcn_perm(x, caz, sa01));
+    const uint32_t t1 = lds_u32(lds, __builtin_amdgcn_perm(x, cbz, sb01));
+    const uint32_t t2 = lds_u32(lds, __builtin_amdgcn_perm(x, caz, sa23) + 128u);
+    const uint32_t t3 = lds_u32(lds, __builtin_amdgcn_perm(x, cbz, sb23) + 128u);
+    return xor3(xor3(t0, t1, t2), t3, d);
+  }
 };
 
 template <int COPIES>
@@ -142,9 +150,9 @@ __device__ __forceinline__ uint4 ld16(uintptr_t p) {
   return make_uint4(v.x, v.y, v.z, v.w);
 }
 
-template <int COPIES, int THREADS>
+template <int COPIES, int ZC, int THREADS>
 __device__ __forceinline__ void build_tables(char* lds, int main_op, int tid) {
-  using L = Lay<COPIES>;
+  using L = Lay<COPIES, ZC>;
   for (int e = tid; e < 1024; e += THREADS) {
     const int j = e >> 8, b = e & 255;  // byte table j, entry b
     uint32_t v = 0, z = 0;
@@ -158,7 +166,14 @@ __device__ __forceinline__ void build_tables(char* lds, int main_op, int tid) {
                                                        : lds + b * 256 + j * 64);
 #pragma unroll
     for (int r = 0; r < COPIES / 4; r++) dst[r] = v4;
-    *reinterpret_cast<uint32_t*>(lds + L::kZ4 + (j * 256 + b) * 4) = z;
+    if (ZC == 1) {
+      *reinterpret_cast<uint32_t*>(lds + L::kZ4 + (j * 256 + b) * 4) = z;
+    } else {
+      const uint4 z4 = make_uint4(z, z, z, z);
+      uint4* dz = reinterpret_cast<uint4*>(lds + L::kZ4 + b * 256 + j * 64);
+#pragma unroll
+      for (int r = 0; r < 4; r++) dz[r] = z4;
+    }
   }
   for (int e = tid; e < kNibOps * 128; e += THREADS) {
     const int op = e >> 7, q = (e >> 4) & 7, nv = e & 15;
@@ -195,10 +210,11 @@ __device__ __forceinline__ uint32_t slot_fold_chain(const char* lds, Z4Addr& ad,
 
 // The library's crc_flat_kernel, compute form without phases: LPW lanes per window, two rows of 64 / LPW windows per
 // wavefront and pass, digests held in HOLD collectors per row until the wavefront's reads are done.
-template <int LPW, int UNR, int COPIES, int THREADS, int WPE, int HOLD, bool LATE>
+template <int LPW, int UNR, int COPIES, int THREADS, int WPE, int HOLD, bool LATE, int ZC = 1>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void flat_kernel(
     const uint8_t* data, uint32_t* sums, uint32_t bpc, uint64_t n_windows) {
-  using L = Lay<COPIES>;
+  static_assert(ZC == 1 || (ZC == 16 && COPIES == 16), "16 copies of the 4-byte operator go with 16 copies of the main tables");
+  using L = Lay<COPIES, ZC>;
   __shared__ __attribute__((aligned(16))) char lds[L::kBytes];
   constexpr int kWaves = THREADS / 64;
   constexpr uint32_t kStripe = 16u * LPW;
@@ -211,7 +227,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WPE, WP
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  build_tables<COPIES, THREADS>(lds, kMainOp, tid);
+  build_tables<COPIES, ZC, THREADS>(lds, kMainOp, tid);
   __syncthreads();
 
   const LaneC<COPIES> lc(lane);
@@ -231,9 +247,25 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WPE, WP
   Acc4 late_a = {0, 0, 0, 0}, late_b = {0, 0, 0, 0};
   bool late = false;
 
+  uint32_t caz = 0, cbz = 0;
+  if constexpr (ZC == 16) {
+    caz = lc.ca + L::kZ4;
+    cbz = lc.cb + L::kZ4;
+  }
   auto fold = [&](const Acc4& fa, const Acc4& fb, uint32_t& x, uint32_t& y) {
-    x = slot_fold_chain(lds, za, fa);
-    y = slot_fold_chain(lds, zb, fb);
+    if constexpr (ZC == 16) {  // the Horner chain through conflict-free copies; the two rows' chains interleave
+      x = lc.gather_at(lds, caz, cbz, fa.a0, fa.a1);
+      y = lc.gather_at(lds, caz, cbz, fb.a0, fb.a1);
+      x = lc.gather_at(lds, caz, cbz, x, fa.a2);
+      y = lc.gather_at(lds, caz, cbz, y, fb.a2);
+      x = lc.gather_at(lds, caz, cbz, x, fa.a3);
+      y = lc.gather_at(lds, caz, cbz, y, fb.a3);
+      x = lc.gather_at(lds, caz, cbz, x, 0u);
+      y = lc.gather_at(lds, caz, cbz, y, 0u);
+    } else {
+      x = slot_fold_chain(lds, za, fa);
+      y = slot_fold_chain(lds, zb, fb);
+    }
 #pragma unroll
     for (int i = 0; i < kLevels; i++) {
       const bool taker = (sl & ((2 << i) - 1)) == (2 << i) - 1;
@@ -378,15 +410,16 @@ struct Config {
   void (*launch)(int blocks, size_t pad, hipStream_t s, const uint8_t* data, uint32_t* sums, uint32_t bpc, uint64_t n);
 };
 
-template <int LPW, int UNR, int COPIES, int THREADS, int WPE, int HOLD, bool LATE>
+template <int LPW, int UNR, int COPIES, int THREADS, int WPE, int HOLD, bool LATE, int ZC>
 static void launch_one(int blocks, size_t pad, hipStream_t s, const uint8_t* data, uint32_t* sums, uint32_t bpc, uint64_t n) {
-  flat_kernel<LPW, UNR, COPIES, THREADS, WPE, HOLD, LATE><<<blocks, THREADS, pad, s>>>(data, sums, bpc, n);
+  flat_kernel<LPW, UNR, COPIES, THREADS, WPE, HOLD, LATE, ZC><<<blocks, THREADS, pad, s>>>(data, sums, bpc, n);
 }
-#define CFG(name, LPW, UNR, COPIES, THREADS, WPE, HOLD, LATE, WGS)                                              \
+#define CFGZ(name, LPW, UNR, COPIES, THREADS, WPE, HOLD, LATE, WGS, ZC)                                         \
   Config {                                                                                                      \
-    name, (const void*)flat_kernel<LPW, UNR, COPIES, THREADS, WPE, HOLD, LATE>, LPW, THREADS, HOLD, WGS,        \
-        (int)Lay<COPIES>::kBytes, launch_one<LPW, UNR, COPIES, THREADS, WPE, HOLD, LATE>                        \
+    name, (const void*)flat_kernel<LPW, UNR, COPIES, THREADS, WPE, HOLD, LATE, ZC>, LPW, THREADS, HOLD, WGS,    \
+        (int)Lay<COPIES, ZC>::kBytes, launch_one<LPW, UNR, COPIES, THREADS, WPE, HOLD, LATE, ZC>                \
   }
+#define CFG(name, LPW, UNR, COPIES, THREADS, WPE, HOLD, LATE, WGS) CFGZ(name, LPW, UNR, COPIES, THREADS, WPE, HOLD, LATE, WGS, 1)
 
 template <int LPW, int UNR>
 static std::vector<Config> configs_for() {
@@ -395,6 +428,8 @@ static std::vector<Config> configs_for() {
       CFG("32 copies, 1024 threads, 1 workgroup/CU, fold one pass late", LPW, UNR, 32, 1024, 4, 8, true, 1),
       CFG("16 copies, 1024 threads, 1 workgroup/CU (LDS padded)", LPW, UNR, 16, 1024, 4, 8, false, 1),
       CFG("16 copies, 1024 threads, 1 workgroup/CU (LDS padded), late fold", LPW, UNR, 16, 1024, 4, 8, true, 1),
+      CFGZ("16 copies + 16 of the 4-byte operator's tables (135 KiB), 1024 threads, 1/CU", LPW, UNR, 16, 1024, 4, 8, false, 1, 16),
+      CFGZ("16 copies + 16 of the 4-byte operator's tables (135 KiB), 1/CU, late fold", LPW, UNR, 16, 1024, 4, 8, true, 1, 16),
       CFG("16 copies,  512 threads, 2 workgroups/CU (4 wavefronts/SIMD)", LPW, UNR, 16, 512, 4, 8, false, 2),
       CFG("16 copies,  512 threads, 2 workgroups/CU, late fold", LPW, UNR, 16, 512, 4, 8, true, 2),
       CFG("16 copies,  768 threads, 2 workgroups/CU (6 wavefronts/SIMD)", LPW, UNR, 16, 768, 6, 8, false, 2),
@@ -420,6 +455,18 @@ int main(int argc, char** argv) {
     case 2048: cfgs = configs_for<8, 1>(); break;
     case 4096: cfgs = configs_for<16, 1>(); break;
     default: fprintf(stderr, "unsupported window size %u\n", bpc); return 1;
+  }
+  if (getenv("SHAPE")) {  // another (lanes per window, stripes per load group) than the library's, e.g. SHAPE=4x4
+    const char* sh = getenv("SHAPE");
+    if (!strcmp(sh, "4x4")) cfgs = configs_for<4, 4>();
+    else if (!strcmp(sh, "4x2")) cfgs = configs_for<4, 2>();
+    else if (!strcmp(sh, "4x1")) cfgs = configs_for<4, 1>();
+    else if (!strcmp(sh, "8x1")) cfgs = configs_for<8, 1>();
+    else if (!strcmp(sh, "8x2")) cfgs = configs_for<8, 2>();
+    else if (!strcmp(sh, "16x1")) cfgs = configs_for<16, 1>();
+    else { fprintf(stderr, "unknown shape %s\n", sh); return 1; }
+    if (bpc % (16u * (sh[0] == '1' ? 16 : sh[0] - '0') * (sh[strlen(sh) - 1] - '0')) != 0) { fprintf(stderr, "shape does not divide the window\n"); return 1; }
+    printf("shape %s\n", sh);
   }
   hipDeviceProp_t prop;
   CK(hipGetDeviceProperties(&prop, 0));
