@@ -16,8 +16,10 @@
 //     stripe does  acc = (acc * x^(8*stripe) mod P) ^ dword.  The multiplication is four
 //     byte-indexed lookups.  The four tables are held in LDS in 32 interleaved copies (copy r of
 //     every entry sits in bank r), so lane l always reads bank l%32: the lookups are conflict-free
-//     whatever the data is, at one LDS lookup per input byte.  The two rows give every wavefront
-//     two independent dependency chains, which keeps the LDS pipeline fed.
+//     whatever the data is, at one LDS lookup per input byte.  (The kernels with several lanes per
+//     window get the same from 16 copies and keep a second table set in the room: kSmallSetBytes.)
+//     The two rows give every wavefront two independent dependency chains, which keeps the LDS
+//     pipeline fed.
 //   * At the end of a window the accumulators are one stripe-sized message with the same CRC
 //     as the window.  It is folded with fixed shift operators: 4 slots -> unit, 64 lanes -> row
 //     (reduction tree over DPP row shifts), 2 rows -> wavefront, G wavefronts -> window (through LDS).
@@ -1240,7 +1242,7 @@ hipError_t crc_launch(const CrcLaunch& launch, int mode, int group, int num_cus,
   }
   const uint64_t per_block = kWaves / group;
   uint64_t blocks = (p.n_windows + per_block - 1) / per_block;
-  if (blocks > (uint64_t)num_cus) blocks = num_cus;  // 139 KiB of LDS: one block per CU, persistent
+  if (blocks > (uint64_t)num_cus) blocks = num_cus;  // 135 KiB of LDS: one block per CU, persistent
   // Default: one stripe ahead.  Deeper prefetch measured slower on MI355X (the kernel is limited by
   // the clock the chip holds under this LDS + HBM load, and more registers in flight cost more).
   switch (g_force_pf) {

@@ -942,7 +942,7 @@ static int init_impl(uint32_t device_mask) {
     if (device_mask && !(device_mask & (1u << i))) continue;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, i) != hipSuccess) continue;
-    // The kernels are built for gfx950 only and need 139 KiB of LDS per workgroup.
+    // The kernels are built for gfx950 only and need 135 KiB of LDS per workgroup.
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) continue;
     DeviceInfo d;
     d.id = i;

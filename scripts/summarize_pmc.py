@@ -34,10 +34,22 @@ def per_step(values):
     return [sum(values[i:i + PER_STEP]) for i in range(0, len(values) - PER_STEP + 1, PER_STEP)]
 
 
+def one_run_only(files):
+    """gpurun merges a call's output into what earlier calls left behind, under file names that carry a process id: two
+    files of one kind in one pass's directory are two runs, and a summary over both would describe neither."""
+    seen = {}
+    for f in files:
+        d = os.path.dirname(f)
+        if d in seen:
+            sys.exit("summarize_pmc: %s and %s are from different runs; delete gpurun_out/prof_* and profile again" % (seen[d], f))
+        seen[d] = f
+    return files
+
+
 def counters():
     agg = collections.defaultdict(list)
     kernel = None
-    for f in sorted(glob.glob(os.path.join(OUT, "prof_%s_pmc_*" % TAG, "**", "*counter_collection.csv"), recursive=True)):
+    for f in one_run_only(sorted(glob.glob(os.path.join(OUT, "prof_%s_pmc_*" % TAG, "**", "*counter_collection.csv"), recursive=True))):
         rows = [r for r in csv.DictReader(open(f)) if KERNEL in r["Kernel_Name"]]
         rows.sort(key=lambda r: int(r["Dispatch_Id"]))
         for r in rows:
@@ -51,12 +63,12 @@ def kernel_times():
     """(average over all profiled launches as rocprofv3 --stats reports it, calls, average without the first WARMUP
     launches from the kernel trace)."""
     avg_ns, calls, warm = None, 0, None
-    for f in glob.glob(os.path.join(OUT, "prof_%s_trace" % TAG, "**", "*kernel_stats.csv"), recursive=True):
+    for f in one_run_only(glob.glob(os.path.join(OUT, "prof_%s_trace" % TAG, "**", "*kernel_stats.csv"), recursive=True)):
         shutil.copy(f, os.path.join(ROOT, "profiles", "%s_kernel_stats_%s.csv" % (os.environ.get("ROUND", "r03"), TAG)))
         for r in csv.DictReader(open(f)):
             if KERNEL in r["Name"] and int(r["Calls"]) > calls * PER_STEP:   # the variant the run is about: the one launched most
                 avg_ns, calls = float(r["AverageNs"]) * PER_STEP, int(r["Calls"]) // PER_STEP
-    for f in glob.glob(os.path.join(OUT, "prof_%s_trace" % TAG, "**", "*kernel_trace.csv"), recursive=True):
+    for f in one_run_only(glob.glob(os.path.join(OUT, "prof_%s_trace" % TAG, "**", "*kernel_trace.csv"), recursive=True)):
         rows = [r for r in csv.DictReader(open(f)) if KERNEL in r["Kernel_Name"]]
         rows.sort(key=lambda r: int(r["Start_Timestamp"]))
         d = per_step([int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows])[WARMUP:]

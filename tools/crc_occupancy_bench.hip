@@ -1,9 +1,9 @@
 // Small CRC windows: would a second workgroup per CU pay?  (gfx950 only; an experiment beside the library, not part of it)
 //
-// The library's CRC kernels keep their four byte tables in LDS in 32 copies (128 KiB), so that lane l always reads bank
-// l % 32; with the fold's tables that is 139 KiB and one workgroup of 16 wavefronts per CU, four per SIMD.  Windows of a
-// few hundred bytes spend most of a pass in the per-window fold (LDS round trips that wait for one another) and in the
-// memory latency a pass begins with; more wavefronts per SIMD would cover both.
+// When this was written the library's CRC kernels all kept their four byte tables in LDS in 32 copies (128 KiB), so that
+// lane l always reads bank l % 32; with the fold's tables that was 139 KiB and one workgroup of 16 wavefronts per CU, four
+// per SIMD.  Windows of a few hundred bytes spend most of a pass in the per-window fold (LDS round trips that wait for one
+// another) and in the memory latency a pass begins with; more wavefronts per SIMD would cover both.
 //
 // 16 copies need not cost bank conflicts: a lookup instruction serves byte k of an accumulator through table k in ALL
 // lanes only by convention -- the four results are XORed, so their order is free.  Here lanes 0-15 of each half of the
@@ -15,6 +15,9 @@
 // This program runs the library's gapless small-window kernel (compute form: digests held in registers until the
 // wavefront's reads are done, optionally the fold one pass late) in both table layouts, with 1024-, 768- and 512-thread
 // workgroups, one or two per CU, checks sampled digests against a bitwise CRC on the host, and prints the rates.
+// Outcome on MI355X: the 16-copy layout is free, the second workgroup buys nothing -- and the room spent on 16 copies of
+// the unit merge's byte tables instead (one copy before: bank conflicts about 3.5 deep) gives 256-byte windows 9 %.  The
+// library's lanes-per-window kernels took that last form.
 //
 // usage: crc_occupancy_bench <bytes per window: 128..4096> [GiB per step, default 8]
 #include <hip/hip_runtime.h>
@@ -424,12 +427,13 @@ static void launch_one(int blocks, size_t pad, hipStream_t s, const uint8_t* dat
 template <int LPW, int UNR>
 static std::vector<Config> configs_for() {
   return {
-      CFG("32 copies, 1024 threads, 1 workgroup/CU (the library's form)", LPW, UNR, 32, 1024, 4, 8, false, 1),
+      CFG("32 copies, 1024 threads, 1 workgroup/CU (the library before this experiment)", LPW, UNR, 32, 1024, 4, 8, false, 1),
       CFG("32 copies, 1024 threads, 1 workgroup/CU, fold one pass late", LPW, UNR, 32, 1024, 4, 8, true, 1),
       CFG("16 copies, 1024 threads, 1 workgroup/CU (LDS padded)", LPW, UNR, 16, 1024, 4, 8, false, 1),
       CFG("16 copies, 1024 threads, 1 workgroup/CU (LDS padded), late fold", LPW, UNR, 16, 1024, 4, 8, true, 1),
-      CFGZ("16 copies + 16 of the 4-byte operator's tables (135 KiB), 1024 threads, 1/CU", LPW, UNR, 16, 1024, 4, 8, false, 1, 16),
-      CFGZ("16 copies + 16 of the 4-byte operator's tables (135 KiB), 1/CU, late fold", LPW, UNR, 16, 1024, 4, 8, true, 1, 16),
+      CFGZ("16 copies + 16 of the unit merge's tables (135 KiB), 1/CU (the library since)", LPW, UNR, 16, 1024, 4, 8, false, 1, 16),
+      CFGZ("16 copies + 16 of the unit merge's tables (135 KiB), 1/CU, late fold", LPW, UNR, 16, 1024, 4, 8, true, 1, 16),
+      CFGZ("16 copies + 16 of the unit merge's tables, 1/CU, 16 collectors per row", LPW, UNR, 16, 1024, 4, 16, false, 1, 16),
       CFG("16 copies,  512 threads, 2 workgroups/CU (4 wavefronts/SIMD)", LPW, UNR, 16, 512, 4, 8, false, 2),
       CFG("16 copies,  512 threads, 2 workgroups/CU, late fold", LPW, UNR, 16, 512, 4, 8, true, 2),
       CFG("16 copies,  768 threads, 2 workgroups/CU (6 wavefronts/SIMD)", LPW, UNR, 16, 768, 6, 8, false, 2),
