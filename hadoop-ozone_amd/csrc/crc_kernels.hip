@@ -308,22 +308,32 @@ __device__ __forceinline__ void build_tables(char* lds, const PolyBasis& pb, int
 
 // The tables of the 16-copy layout: the byte tables of operator `main_op` and of "advance 4 bytes", and the nibble
 // tables of operators 0..kNibOps-1.  All kThreads threads take part.
+// A thread owns entry b of table j in the stripe set and entry b of table j ^ 1 in the other set: the two lie in
+// different halves of the banks.  A 16-byte store is served eight lanes at a time, and the eight have the same j and
+// consecutive b, i.e. addresses 256 bytes apart: written in table order they would all meet in one group of four banks
+// (eight deep; with a batch cut into 16-32 launches the build was 2-3 % of a launch at 128- and 256-byte windows).  So
+// even lanes store into the first set while odd lanes store into the second, each starting at a different quarter of
+// its 64 bytes: the eight lanes of a group write eight different bank groups.
 __device__ __forceinline__ void build_small_tables(char* lds, const PolyBasis& pb, int main_op, int tid) {
-  const int j = tid >> 8, b = tid & 255;  // byte table j, entry b
+  const int j = tid >> 8, b = tid & 255;  // byte table j (uniform over a wavefront), entry b
   uint32_t v = 0, z = 0;
 #pragma unroll
   for (int i = 0; i < 8; i++) {
     v ^= ((b >> i) & 1) ? pb.op[main_op].v[8 * j + i] : 0u;
-    z ^= ((b >> i) & 1) ? pb.op[kOpZ4].v[8 * j + i] : 0u;
+    z ^= ((b >> i) & 1) ? pb.op[kOpZ4].v[8 * (j ^ 1) + i] : 0u;
   }
-  uint4* dv = reinterpret_cast<uint4*>(lds + b * 256 + j * 64);
-  uint4* dz = reinterpret_cast<uint4*>(lds + kSmallZ4Off + b * 256 + j * 64);
-  const uint4 v4 = make_uint4(v, v, v, v), z4 = make_uint4(z, z, z, z);
+  char* dv = lds + b * 256 + j * 64;
+  char* dz = lds + kSmallZ4Off + b * 256 + (j ^ 1) * 64;
+  const bool odd = (tid & 1) != 0;
+  const int rot = (tid >> 1) & 3;
+  char* first = odd ? dz : dv;
+  char* second = odd ? dv : dz;
+  const uint32_t fv = odd ? z : v, sv = odd ? v : z;
+  const uint4 f4 = make_uint4(fv, fv, fv, fv), s4 = make_uint4(sv, sv, sv, sv);
 #pragma unroll
-  for (int r = 0; r < 4; r++) {
-    dv[r] = v4;
-    dz[r] = z4;
-  }
+  for (int r = 0; r < 4; r++) *reinterpret_cast<uint4*>(first + ((r + rot) & 3) * 16) = f4;
+#pragma unroll
+  for (int r = 0; r < 4; r++) *reinterpret_cast<uint4*>(second + ((r + rot) & 3) * 16) = s4;
   for (int e = tid; e < kNibOps * 128; e += kThreads) {
     const int op = e >> 7, q = (e >> 4) & 7, nv = e & 15;
     uint32_t w = 0;
@@ -1037,22 +1047,25 @@ hipError_t launch_flat(const CrcLaunch& p, int lpw, int unr, int phases, int blo
   return hipGetLastError();
 }
 
-// The compute forms that hold their digests until a wavefront's reads are done; kFlatHold collectors per row.
-constexpr int kFlatHold = 8;
+// The compute forms that hold their digests until a wavefront's reads are done; flat_hold(lanes) collectors per row.
+// Sixteen with 4 lanes per window, where a collector is full after 4 passes: 128-byte windows then leave in launches of
+// 1 GiB instead of 512 MiB, and a launch's fixed cost (table build, first and last pass) weighs half as much
+// (MI355X: +2 % at 128 B; with 8 lanes and more it changes nothing).
+constexpr int flat_hold(int lanes) { return lanes == 4 ? 16 : 8; }
 hipError_t launch_flat_hold(const CrcLaunch& p, int lpw, int unr, int phases, int blocks, hipStream_t stream) {
   if (phases == 4) {
-    if (lpw == 8 && unr == 1) crc_flat_kernel<8, kModeCompute, 1, 4, kFlatHold><<<blocks, kThreads, 0, stream>>>(p);
+    if (lpw == 8 && unr == 1) crc_flat_kernel<8, kModeCompute, 1, 4, flat_hold(8)><<<blocks, kThreads, 0, stream>>>(p);
     else return hipErrorInvalidValue;
     return hipGetLastError();
   }
   switch (lpw * 8 + unr) {
-    case 4 * 8 + 1: crc_flat_kernel<4, kModeCompute, 1, 1, kFlatHold><<<blocks, kThreads, 0, stream>>>(p); break;
-    case 4 * 8 + 2: crc_flat_kernel<4, kModeCompute, 2, 1, kFlatHold><<<blocks, kThreads, 0, stream>>>(p); break;
-    case 8 * 8 + 1: crc_flat_kernel<8, kModeCompute, 1, 1, kFlatHold><<<blocks, kThreads, 0, stream>>>(p); break;
-    case 8 * 8 + 2: crc_flat_kernel<8, kModeCompute, 2, 1, kFlatHold><<<blocks, kThreads, 0, stream>>>(p); break;
-    case 16 * 8 + 1: crc_flat_kernel<16, kModeCompute, 1, 1, kFlatHold><<<blocks, kThreads, 0, stream>>>(p); break;
-    case 16 * 8 + 2: crc_flat_kernel<16, kModeCompute, 2, 1, kFlatHold><<<blocks, kThreads, 0, stream>>>(p); break;
-    case 32 * 8 + 1: crc_flat_kernel<32, kModeCompute, 1, 1, kFlatHold><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 4 * 8 + 1: crc_flat_kernel<4, kModeCompute, 1, 1, flat_hold(4)><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 4 * 8 + 2: crc_flat_kernel<4, kModeCompute, 2, 1, flat_hold(4)><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 8 * 8 + 1: crc_flat_kernel<8, kModeCompute, 1, 1, flat_hold(8)><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 8 * 8 + 2: crc_flat_kernel<8, kModeCompute, 2, 1, flat_hold(8)><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 16 * 8 + 1: crc_flat_kernel<16, kModeCompute, 1, 1, flat_hold(16)><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 16 * 8 + 2: crc_flat_kernel<16, kModeCompute, 2, 1, flat_hold(16)><<<blocks, kThreads, 0, stream>>>(p); break;
+    case 32 * 8 + 1: crc_flat_kernel<32, kModeCompute, 1, 1, flat_hold(32)><<<blocks, kThreads, 0, stream>>>(p); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -1201,11 +1214,11 @@ hipError_t crc_launch(const CrcLaunch& launch, int mode, int group, int num_cus,
       // on MI355X: verify, which writes none, runs at 6.5 / 7.0 / 7.1 / 7.0 TB/s at 512 B / 1 / 2 / 4 KiB where compute with
       // its stores in the stream ran at 6.0 / 6.3 / 6.65 / 6.7; from 8 KiB on the two are level, but for 16 KiB, where
       // the phased form reads faster than its neighbours and the stores showed again: 6.92 against 7.01).  A wavefront holds
-      // kFlatHold * lanes passes; a larger batch is cut into launches of that many passes over the whole grid.
+      // flat_hold(lanes) * lanes passes; a larger batch is cut into launches of that many passes over the whole grid.
       if (mode == kModeCompute && g_force_hold >= 0 && (p.bpc <= 4096 || p.bpc == 16384 || g_force_hold > 0) &&
           p.bpc % (16u * fl * fu) == 0) {
         const uint64_t per_pass = (uint64_t)num_cus * kWaves * 2 * (64 / fl);  // windows of one pass of a full grid
-        const uint64_t cap = per_pass * (uint64_t)(kFlatHold * fl);
+        const uint64_t cap = per_pass * (uint64_t)(flat_hold(fl) * fl);
         const uint64_t launches = (p.n_windows + cap - 1) / cap;
         uint64_t share = (p.n_windows + launches - 1) / launches;  // equal shares, whole passes
         share = (share + per_pass - 1) / per_pass * per_pass;

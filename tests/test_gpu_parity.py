@@ -996,11 +996,11 @@ def test_default_kernel_selection_four_phase_flat_crc(gpu, t, bpc, gib):
 
 
 
-@pytest.mark.parametrize("bpc,mib", [(512, 320), (128, 640), (4096, 600), (256, 100)])
+@pytest.mark.parametrize("bpc,mib", [(512, 320), (128, 1100), (128, 70), (4096, 600), (256, 100)])
 def test_compute_small_windows_digests_held_to_the_end_of_a_wavefronts_reads(gpu, bpc, mib):
     # compute at windows of 4 KiB and less keeps a wavefront's digests in registers and stores them when its reads are
     # done: several passes per wavefront (more than one collector register), a batch that needs more than one launch
-    # (128 B x 640 MiB), a last pass that is not full, and every digest against the oracle
+    # (128 B x 1,100 MiB: a launch of 4-lane windows takes 1 GiB), a last pass that is not full, and every digest against the oracle
     torch, native, L = gpu
     n = mib * (1 << 20) + 3 * bpc          # a ragged number of windows: the last pass is partial
     host = oracle.splitmix64(900 + bpc, n)
