@@ -10,12 +10,14 @@
 
 #define UNROLL 64
 
-template <int KIND>
+// HALF: only lanes 0-31 of every wavefront execute the loop (does an instruction whose upper half is masked off issue faster?)
+template <int KIND, bool HALF = false>
 __global__ void bench(uint32_t* out, uint64_t* cycles, uint32_t seed, int REP) {
   uint32_t a = seed + threadIdx.x, b = seed * 3 + threadIdx.x, c = seed * 7, d = seed * 11 + threadIdx.x;
   asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
   uint64_t t0;
   asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory");
+  if (HALF && (threadIdx.x & 32)) REP = 0;
   for (int r = 0; r < REP; r++) {
 #pragma unroll
     for (int i = 0; i < UNROLL; i++) {
@@ -47,7 +49,7 @@ __global__ void bench(uint32_t* out, uint64_t* cycles, uint32_t seed, int REP) {
   if (threadIdx.x == 0) cycles[0] = t1 - t0;
 }
 
-template <int KIND>
+template <int KIND, bool HALF = false>
 void run(const char* name, int per_iter, uint32_t* out, uint64_t* cyc, int waves) {
   const int REP = 20000;
   hipEvent_t e0, e1;
@@ -56,7 +58,7 @@ void run(const char* name, int per_iter, uint32_t* out, uint64_t* cyc, int waves
   float ms = 0;
   for (int rep = 0; rep < 3; rep++) {
     CK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL(bench<KIND>, dim3(1), dim3(64 * waves), 0, 0, out, cyc, 12345u + rep, REP);
+    hipLaunchKernelGGL((bench<KIND, HALF>), dim3(1), dim3(64 * waves), 0, 0, out, cyc, 12345u + rep, REP);
     CK(hipEventRecord(e1, 0));
     CK(hipDeviceSynchronize());
     CK(hipEventElapsedTime(&ms, e0, e1));
@@ -72,7 +74,7 @@ int main() {
   uint64_t* cyc;
   CK(hipMalloc(&out, 4096 * 4));
   CK(hipMalloc(&cyc, 8));
-  for (int waves : {1, 4, 8}) {
+  for (int waves : {1, 4, 8, 16}) {
     run<0>("dependent v_add_u32", 4, out, cyc, waves);
     run<1>("4 independent v_add_u32 (literal)", 4, out, cyc, waves);
     run<2>("dependent v_alignbit_b32", 4, out, cyc, waves);
@@ -80,6 +82,10 @@ int main() {
     run<3>("dependent v_bitop3_b32", 4, out, cyc, waves);
     run<4>("dependent v_add3_u32 (sgpr operand)", 4, out, cyc, waves);
     run<5>("MD5 step shape (5 dependent)", 5, out, cyc, waves);
+    run<0, true>("dependent v_add_u32, lanes 32-63 masked off", 4, out, cyc, waves);
+    run<1, true>("4 independent v_add_u32, lanes 32-63 masked off", 4, out, cyc, waves);
+    run<2, true>("dependent v_alignbit_b32, lanes 32-63 masked off", 4, out, cyc, waves);
+    run<4, true>("dependent v_add3_u32, lanes 32-63 masked off", 4, out, cyc, waves);
   }
   return 0;
 }
