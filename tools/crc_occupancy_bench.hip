@@ -213,7 +213,7 @@ __device__ __forceinline__ uint32_t slot_fold_chain(const char* lds, Z4Addr& ad,
 
 // The library's crc_flat_kernel, compute form without phases: LPW lanes per window, two rows of 64 / LPW windows per
 // wavefront and pass, digests held in HOLD collectors per row until the wavefront's reads are done.
-template <int LPW, int UNR, int COPIES, int THREADS, int WPE, int HOLD, bool LATE, int ZC = 1>
+template <int LPW, int UNR, int COPIES, int THREADS, int WPE, int HOLD, bool LATE, int ZC = 1, bool PRE = false>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void flat_kernel(
     const uint8_t* data, uint32_t* sums, uint32_t bpc, uint64_t n_windows) {
   static_assert(ZC == 1 || (ZC == 16 && COPIES == 16), "16 copies of the 4-byte operator go with 16 copies of the main tables");
@@ -295,6 +295,44 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WPE, WP
     }
   };
 
+  if constexpr (PRE) {
+    // A whole window is one load group (the host checks bpc == kGroup): the next pass's windows are requested before the
+    // current pass's arithmetic, two register buffers taking turns.
+    const uint64_t stride = (uint64_t)gridDim.x * kWaves * kWinPerWave;
+    uint64_t w0 = ((uint64_t)blockIdx.x * kWaves + wave) * kWinPerWave;
+    auto load = [&](uint4 (&da)[UNR], uint4 (&db)[UNR], uint64_t w) {
+      const uint64_t ga = w + grp, gb = w + kWinPerRow + grp;
+      const uintptr_t wa = base + (ga < last ? ga : last) * bpc, wb = base + (gb < last ? gb : last) * bpc;
+#pragma unroll
+      for (int k = 0; k < UNR; k++) {
+        da[k] = ld16(wa + k * kStripe);
+        db[k] = ld16(wb + k * kStripe);
+      }
+    };
+    auto work = [&](const uint4 (&da)[UNR], const uint4 (&db)[UNR]) {
+      Acc4 a = {da[0].x ^ init, da[0].y, da[0].z, da[0].w};
+      Acc4 b = {db[0].x ^ init, db[0].y, db[0].z, db[0].w};
+#pragma unroll
+      for (int k = 1; k < UNR; k++) {
+        absorb<COPIES>(lds, lc, a, da[k]);
+        absorb<COPIES>(lds, lc, b, db[k]);
+      }
+      uint32_t x, y;
+      fold(a, b, x, y);
+      collect(x, y);
+    };
+    uint4 pa[UNR], pb[UNR], qa[UNR], qb[UNR];
+    if (w0 < n_windows) load(pa, pb, w0);
+    while (w0 < n_windows) {
+      if (w0 + stride < n_windows) load(qa, qb, w0 + stride);
+      work(pa, pb);
+      w0 += stride;
+      if (w0 >= n_windows) break;
+      if (w0 + stride < n_windows) load(pa, pb, w0 + stride);
+      work(qa, qb);
+      w0 += stride;
+    }
+  } else
   for (uint64_t w0 = ((uint64_t)blockIdx.x * kWaves + wave) * kWinPerWave; w0 < n_windows;
        w0 += (uint64_t)gridDim.x * kWaves * kWinPerWave) {
     const uint64_t ga = w0 + grp, gb = w0 + kWinPerRow + grp;
@@ -411,16 +449,22 @@ struct Config {
   const void* fn;
   int lpw, threads, hold, wgs_per_cu, table_bytes;
   void (*launch)(int blocks, size_t pad, hipStream_t s, const uint8_t* data, uint32_t* sums, uint32_t bpc, uint64_t n);
+  uint32_t only_bpc = 0;  // a form built for one window size only
 };
 
-template <int LPW, int UNR, int COPIES, int THREADS, int WPE, int HOLD, bool LATE, int ZC>
+template <int LPW, int UNR, int COPIES, int THREADS, int WPE, int HOLD, bool LATE, int ZC, bool PRE = false>
 static void launch_one(int blocks, size_t pad, hipStream_t s, const uint8_t* data, uint32_t* sums, uint32_t bpc, uint64_t n) {
-  flat_kernel<LPW, UNR, COPIES, THREADS, WPE, HOLD, LATE, ZC><<<blocks, THREADS, pad, s>>>(data, sums, bpc, n);
+  flat_kernel<LPW, UNR, COPIES, THREADS, WPE, HOLD, LATE, ZC, PRE><<<blocks, THREADS, pad, s>>>(data, sums, bpc, n);
 }
 #define CFGZ(name, LPW, UNR, COPIES, THREADS, WPE, HOLD, LATE, WGS, ZC)                                         \
   Config {                                                                                                      \
     name, (const void*)flat_kernel<LPW, UNR, COPIES, THREADS, WPE, HOLD, LATE, ZC>, LPW, THREADS, HOLD, WGS,    \
         (int)Lay<COPIES, ZC>::kBytes, launch_one<LPW, UNR, COPIES, THREADS, WPE, HOLD, LATE, ZC>                \
+  }
+#define CFGP(name, LPW, UNR, HOLD)                                                                              \
+  Config {                                                                                                      \
+    name, (const void*)flat_kernel<LPW, UNR, 16, 1024, 4, HOLD, false, 16, true>, LPW, 1024, HOLD, 1,           \
+        (int)Lay<16, 16>::kBytes, launch_one<LPW, UNR, 16, 1024, 4, HOLD, false, 16, true>, 16u * LPW * UNR       \
   }
 #define CFG(name, LPW, UNR, COPIES, THREADS, WPE, HOLD, LATE, WGS) CFGZ(name, LPW, UNR, COPIES, THREADS, WPE, HOLD, LATE, WGS, 1)
 
@@ -434,6 +478,7 @@ static std::vector<Config> configs_for() {
       CFGZ("16 copies + 16 of the unit merge's tables (135 KiB), 1/CU (the library since)", LPW, UNR, 16, 1024, 4, 8, false, 1, 16),
       CFGZ("16 copies + 16 of the unit merge's tables (135 KiB), 1/CU, late fold", LPW, UNR, 16, 1024, 4, 8, true, 1, 16),
       CFGZ("16 copies + 16 of the unit merge's tables, 1/CU, 16 collectors per row", LPW, UNR, 16, 1024, 4, 16, false, 1, 16),
+      CFGP("16 + 16 copies, 1/CU, the next pass's windows requested a pass ahead (whole window = one load group)", LPW, UNR, 8),
       CFG("16 copies,  512 threads, 2 workgroups/CU (4 wavefronts/SIMD)", LPW, UNR, 16, 512, 4, 8, false, 2),
       CFG("16 copies,  512 threads, 2 workgroups/CU, late fold", LPW, UNR, 16, 512, 4, 8, true, 2),
       CFG("16 copies,  768 threads, 2 workgroups/CU (6 wavefronts/SIMD)", LPW, UNR, 16, 768, 6, 8, false, 2),
@@ -496,6 +541,7 @@ int main(int argc, char** argv) {
   cfgs.insert(cfgs.begin(), cfgs.front());
   bool discard = true;
   for (const Config& c : cfgs) {
+    if (c.only_bpc && c.only_bpc != bpc) continue;
     hipFuncAttributes fa;
     CK(hipFuncGetAttributes(&fa, c.fn));
     // dynamic LDS on top of the tables, so that exactly wgs_per_cu workgroups fit a CU
