@@ -213,7 +213,7 @@ __device__ __forceinline__ uint32_t slot_fold_chain(const char* lds, Z4Addr& ad,
 
 // The library's crc_flat_kernel, compute form without phases: LPW lanes per window, two rows of 64 / LPW windows per
 // wavefront and pass, digests held in HOLD collectors per row until the wavefront's reads are done.
-template <int LPW, int UNR, int COPIES, int THREADS, int WPE, int HOLD, bool LATE, int ZC = 1, bool PRE = false>
+template <int LPW, int UNR, int COPIES, int THREADS, int WPE, int HOLD, bool LATE, int ZC = 1, bool PRE = false, int CUT = 0>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void flat_kernel(
     const uint8_t* data, uint32_t* sums, uint32_t bpc, uint64_t n_windows) {
   static_assert(ZC == 1 || (ZC == 16 && COPIES == 16), "16 copies of the 4-byte operator go with 16 copies of the main tables");
@@ -255,8 +255,12 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WPE, WP
     caz = lc.ca + L::kZ4;
     cbz = lc.cb + L::kZ4;
   }
+  // CUT (timing only, digests wrong on purpose): 1 no unit merge, 2 no lane tree, 3 neither
   auto fold = [&](const Acc4& fa, const Acc4& fb, uint32_t& x, uint32_t& y) {
-    if constexpr (ZC == 16) {  // the Horner chain through conflict-free copies; the two rows' chains interleave
+    if constexpr ((CUT & 1) != 0) {
+      x = fa.a0 ^ fa.a1 ^ fa.a2 ^ fa.a3;
+      y = fb.a0 ^ fb.a1 ^ fb.a2 ^ fb.a3;
+    } else if constexpr (ZC == 16) {  // the Horner chain through conflict-free copies; the two rows' chains interleave
       x = lc.gather_at(lds, caz, cbz, fa.a0, fa.a1);
       y = lc.gather_at(lds, caz, cbz, fb.a0, fb.a1);
       x = lc.gather_at(lds, caz, cbz, x, fa.a2);
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WPE, WP
       y = slot_fold_chain(lds, zb, fb);
     }
 #pragma unroll
-    for (int i = 0; i < kLevels; i++) {
+    for (int i = 0; i < ((CUT & 2) ? 0 : kLevels); i++) {
       const bool taker = (sl & ((2 << i) - 1)) == (2 << i) - 1;
       const uint32_t below = lanes_up(x, i);
       const uint32_t t = nib_apply<L::kNib>(lds, kOpZ16 + i, taker ? below : y);
@@ -450,11 +454,12 @@ struct Config {
   int lpw, threads, hold, wgs_per_cu, table_bytes;
   void (*launch)(int blocks, size_t pad, hipStream_t s, const uint8_t* data, uint32_t* sums, uint32_t bpc, uint64_t n);
   uint32_t only_bpc = 0;  // a form built for one window size only
+  bool timing_only = false;  // a part of the fold is left out: the digests are wrong on purpose
 };
 
-template <int LPW, int UNR, int COPIES, int THREADS, int WPE, int HOLD, bool LATE, int ZC, bool PRE = false>
+template <int LPW, int UNR, int COPIES, int THREADS, int WPE, int HOLD, bool LATE, int ZC, bool PRE = false, int CUT = 0>
 static void launch_one(int blocks, size_t pad, hipStream_t s, const uint8_t* data, uint32_t* sums, uint32_t bpc, uint64_t n) {
-  flat_kernel<LPW, UNR, COPIES, THREADS, WPE, HOLD, LATE, ZC, PRE><<<blocks, THREADS, pad, s>>>(data, sums, bpc, n);
+  flat_kernel<LPW, UNR, COPIES, THREADS, WPE, HOLD, LATE, ZC, PRE, CUT><<<blocks, THREADS, pad, s>>>(data, sums, bpc, n);
 }
 #define CFGZ(name, LPW, UNR, COPIES, THREADS, WPE, HOLD, LATE, WGS, ZC)                                         \
   Config {                                                                                                      \
@@ -465,6 +470,11 @@ static void launch_one(int blocks, size_t pad, hipStream_t s, const uint8_t* dat
   Config {                                                                                                      \
     name, (const void*)flat_kernel<LPW, UNR, 16, 1024, 4, HOLD, false, 16, true>, LPW, 1024, HOLD, 1,           \
         (int)Lay<16, 16>::kBytes, launch_one<LPW, UNR, 16, 1024, 4, HOLD, false, 16, true>, 16u * LPW * UNR       \
+  }
+#define CFGC(name, LPW, UNR, LATE, CUT)                                                                         \
+  Config {                                                                                                      \
+    name, (const void*)flat_kernel<LPW, UNR, 16, 1024, 4, 8, LATE, 16, false, CUT>, LPW, 1024, 8, 1,            \
+        (int)Lay<16, 16>::kBytes, launch_one<LPW, UNR, 16, 1024, 4, 8, LATE, 16, false, CUT>, 0, true            \
   }
 #define CFG(name, LPW, UNR, COPIES, THREADS, WPE, HOLD, LATE, WGS) CFGZ(name, LPW, UNR, COPIES, THREADS, WPE, HOLD, LATE, WGS, 1)
 
@@ -479,6 +489,10 @@ static std::vector<Config> configs_for() {
       CFGZ("16 copies + 16 of the unit merge's tables (135 KiB), 1/CU, late fold", LPW, UNR, 16, 1024, 4, 8, true, 1, 16),
       CFGZ("16 copies + 16 of the unit merge's tables, 1/CU, 16 collectors per row", LPW, UNR, 16, 1024, 4, 16, false, 1, 16),
       CFGP("16 + 16 copies, 1/CU, the next pass's windows requested a pass ahead (whole window = one load group)", LPW, UNR, 8),
+      CFGC("  timing only: the library's form without the unit merge", LPW, UNR, false, 1),
+      CFGC("  timing only: without the lane tree", LPW, UNR, false, 2),
+      CFGC("  timing only: without either (the loop, the loads, the stripe lookups, the collectors)", LPW, UNR, false, 3),
+      CFGC("  timing only: late fold, without either", LPW, UNR, true, 3),
       CFG("16 copies,  512 threads, 2 workgroups/CU (4 wavefronts/SIMD)", LPW, UNR, 16, 512, 4, 8, false, 2),
       CFG("16 copies,  512 threads, 2 workgroups/CU, late fold", LPW, UNR, 16, 512, 4, 8, true, 2),
       CFG("16 copies,  768 threads, 2 workgroups/CU (6 wavefronts/SIMD)", LPW, UNR, 16, 768, 6, 8, false, 2),
@@ -575,7 +589,7 @@ int main(int argc, char** argv) {
       uint64_t w = k == 0 ? 0 : k == 1 ? n_all - 1 : k == 2 ? share - 1 : k == 3 ? share : mix32(k);  // ends of launches, then anywhere
       w %= n_all;
       checked++;
-      if (got[w] != host_digest(w, bpc)) {
+      if (!c.timing_only && got[w] != host_digest(w, bpc)) {
         if (bad++ < 3) fprintf(stderr, "  window %llu: %08x, host %08x\n", (unsigned long long)w, got[w], host_digest(w, bpc));
       }
     }
@@ -593,7 +607,7 @@ int main(int argc, char** argv) {
     }
     printf("%-82s %3d VGPRs, %4d B spilled, %d resident/CU, %llu launches a step: %5.2f TB/s  digests %s (%llu sampled)\n",
            c.name, fa.numRegs, (int)fa.localSizeBytes, resident, (unsigned long long)launches, tbs,
-           bad ? "WRONG" : "ok", (unsigned long long)checked);
+           c.timing_only ? "not checked" : bad ? "WRONG" : "ok", (unsigned long long)checked);
     fflush(stdout);
     if (bad) return 3;
   }
