@@ -504,7 +504,7 @@ static std::vector<Config> configs_for() {
 
 int main(int argc, char** argv) {
   if (argc < 2) {
-    fprintf(stderr, "usage: %s <bytes per window: 128, 256, 512, 1024, 2048 or 4096> [GiB per step]\n", argv[0]);
+    fprintf(stderr, "usage: %s <bytes per window: 128, 256, 512, 1024, 2048, 4096 or 8192> [GiB per step]\n", argv[0]);
     return 1;
   }
   const uint32_t bpc = (uint32_t)atoi(argv[1]);
@@ -517,6 +517,7 @@ int main(int argc, char** argv) {
     case 1024: cfgs = configs_for<8, 1>(); break;
     case 2048: cfgs = configs_for<8, 1>(); break;
     case 4096: cfgs = configs_for<16, 1>(); break;
+    case 8192: cfgs = configs_for<16, 2>(); break;
     default: fprintf(stderr, "unsupported window size %u\n", bpc); return 1;
   }
   if (getenv("SHAPE")) {  // another (lanes per window, stripes per load group) than the library's, e.g. SHAPE=4x4
@@ -527,8 +528,10 @@ int main(int argc, char** argv) {
     else if (!strcmp(sh, "8x1")) cfgs = configs_for<8, 1>();
     else if (!strcmp(sh, "8x2")) cfgs = configs_for<8, 2>();
     else if (!strcmp(sh, "16x1")) cfgs = configs_for<16, 1>();
+    else if (!strcmp(sh, "16x2")) cfgs = configs_for<16, 2>();
+    else if (!strcmp(sh, "32x1")) cfgs = configs_for<32, 1>();
     else { fprintf(stderr, "unknown shape %s\n", sh); return 1; }
-    if (bpc % (16u * (sh[0] == '1' ? 16 : sh[0] - '0') * (sh[strlen(sh) - 1] - '0')) != 0) { fprintf(stderr, "shape does not divide the window\n"); return 1; }
+    if (bpc % (16u * (sh[0] == '1' ? 16 : sh[0] == '3' ? 32 : sh[0] - '0') * (sh[strlen(sh) - 1] - '0')) != 0) { fprintf(stderr, "shape does not divide the window\n"); return 1; }
     printf("shape %s\n", sh);
   }
   hipDeviceProp_t prop;
