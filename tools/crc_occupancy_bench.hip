@@ -336,11 +336,26 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WPE, WP
       work(qa, qb);
       w0 += stride;
     }
-  } else
+  } else {
+#ifdef INCR_ADDR  // A/B build (-DINCR_ADDR): window addresses by increment, the clamp only in a wavefront's last, partial pass.
+                  // Measured: no difference at any window size (the pass's floor is not its address arithmetic).
+  const uint64_t stride_w = (uint64_t)gridDim.x * kWaves * kWinPerWave;
+  const uint64_t step_bytes = stride_w * bpc;
+  uint64_t w0 = ((uint64_t)blockIdx.x * kWaves + wave) * kWinPerWave;
+  uintptr_t pa = base + (w0 + grp) * bpc, pb = pa + (uint64_t)kWinPerRow * bpc;
+  for (; w0 < n_windows; w0 += stride_w, pa += step_bytes, pb += step_bytes) {
+    uintptr_t wa = pa, wb = pb;
+    if (w0 + kWinPerWave > n_windows) {
+      const uint64_t ga = w0 + grp, gb = w0 + kWinPerRow + grp;
+      wa = base + (ga < last ? ga : last) * bpc;
+      wb = base + (gb < last ? gb : last) * bpc;
+    }
+#else
   for (uint64_t w0 = ((uint64_t)blockIdx.x * kWaves + wave) * kWinPerWave; w0 < n_windows;
        w0 += (uint64_t)gridDim.x * kWaves * kWinPerWave) {
     const uint64_t ga = w0 + grp, gb = w0 + kWinPerRow + grp;
     const uintptr_t wa = base + (ga < last ? ga : last) * bpc, wb = base + (gb < last ? gb : last) * bpc;
+#endif
     uint4 ca[UNR], cb[UNR], na[UNR], nb[UNR];
     uintptr_t ua = wa, ub = wb;
 #pragma unroll
@@ -400,6 +415,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WPE, WP
     uint32_t x, y;
     fold(a, b, x, y);
     collect(x, y);
+  }
   }
   if (LATE && late) {
     uint32_t x, y;
