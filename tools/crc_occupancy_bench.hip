@@ -325,16 +325,21 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WPE, WP
       fold(a, b, x, y);
       collect(x, y);
     };
-    uint4 pa[UNR], pb[UNR], qa[UNR], qb[UNR];
+    // One buffer in use, one on its way; the copy at the end of a pass is what the next pass reads, so the request cannot
+    // be moved behind the arithmetic it is meant to overlap (requests that are used in the same loop iteration were:
+    // the compiler sank them to just in front of their first use).  Windows beyond the end are clamped to the last one,
+    // so the request is unconditional.
+    uint4 pa[UNR], pb[UNR];
     if (w0 < n_windows) load(pa, pb, w0);
-    while (w0 < n_windows) {
-      if (w0 + stride < n_windows) load(qa, qb, w0 + stride);
+    for (; w0 < n_windows; w0 += stride) {
+      uint4 qa[UNR], qb[UNR];
+      load(qa, qb, w0 + stride);
       work(pa, pb);
-      w0 += stride;
-      if (w0 >= n_windows) break;
-      if (w0 + stride < n_windows) load(pa, pb, w0 + stride);
-      work(qa, qb);
-      w0 += stride;
+#pragma unroll
+      for (int k = 0; k < UNR; k++) {
+        pa[k] = qa[k];
+        pb[k] = qb[k];
+      }
     }
   } else {
 #ifdef INCR_ADDR  // A/B build (-DINCR_ADDR): window addresses by increment, the clamp only in a wavefront's last, partial pass.
